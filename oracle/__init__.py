@@ -1,0 +1,352 @@
+"""ctypes bindings for the two CPU checkers.  TEST INFRASTRUCTURE ONLY.
+
+``load("oracle")`` -> oracle/libptoracle.so   (plain-C restatement, oracle/pt_oracle.c)
+``load("ref")``    -> oracle/_ref/libptref.so (the compiled, unmodified reference behind oracle/ref_shim.cpp)
+
+Both expose the same entry points (prefix ``oracle_`` / ``ref_``), wrapped here by one class so a test can run the same
+harness against either.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+OBJ_TRIANGLE, OBJ_SPHERE = 0, 1
+BSDF_LAMBERTIAN, BSDF_GLASS, BSDF_MIRROR = 0, 1, 2
+APERTURE_NONE, APERTURE_CIRCULAR, APERTURE_HEXAGONAL = 0, 1, 2
+NO_MATERIAL = 0xFFFFFFFF
+
+
+class Material(C.Structure):
+    _fields_ = [("diffuse", C.c_float * 4), ("specular", C.c_float * 4), ("emission", C.c_float * 4), ("ior", C.c_float),
+                ("bsdf", C.c_int32), ("one_way", C.c_int32), ("pad", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_objects", C.c_uint32), ("obj_kind", C.c_void_p),
+                ("n_triangles", C.c_uint32), ("tri_pos", C.c_void_p), ("tri_nrm", C.c_void_p), ("tri_cull", C.c_void_p),
+                ("tri_material", C.c_void_p),
+                ("n_spheres", C.c_uint32), ("sph", C.c_void_p), ("sph_material", C.c_void_p),
+                ("n_materials", C.c_uint32), ("materials", C.c_void_p),
+                ("n_point_lights", C.c_uint32), ("light_pos", C.c_void_p), ("light_spectrum", C.c_void_p)]
+
+
+class CameraParams(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("look_at", C.c_float * 3), ("up", C.c_float * 3), ("focal_length", C.c_float),
+                ("height", C.c_float), ("aspect_ratio", C.c_float), ("aperture_width", C.c_float), ("aperture_height", C.c_float),
+                ("aperture_kind", C.c_int32), ("hex_ratio", C.c_float), ("focal_plane_dist", C.c_float)]
+
+
+class Options(C.Structure):
+    _fields_ = [("image_width", C.c_int32), ("image_height", C.c_int32), ("min_sample_count", C.c_int32),
+                ("max_sample_count", C.c_int32), ("epsilon", C.c_float)]
+
+
+class Stream(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("rng_state", C.c_uint64)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("scene_queries", C.c_uint64), ("aabb_tests", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("vertices", C.c_uint64), ("shadow_rays", C.c_uint64)]
+
+
+STREAM_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("rng_state", "<u8")])
+MATERIAL_DTYPE = np.dtype([("diffuse", "<f4", 4), ("specular", "<f4", 4), ("emission", "<f4", 4), ("ior", "<f4"), ("bsdf", "<i4"),
+                           ("one_way", "<i4"), ("pad", "<i4")])
+
+
+def seed_to_state(seed):
+    """RandomEngine(seed) raw state, /root/reference/include/PathTrace/base.h:26."""
+    seed &= 0xFFFFFFFFFFFFFFFF
+    return seed ^ ((~seed << 32) & 0xFFFFFFFFFFFFFFFF)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+def build():
+    """Compile the checkers (oracle always; oracle/_ref only where /root/reference exists)."""
+    subprocess.run(["make", "-s", "-C", HERE], check=True)
+
+
+def scene_desc(scene):
+    """ctypes view of a scene dict (see cpupathtrace_amd.scenes); returns (desc, keepalive)."""
+    keep = {
+        "obj_kind": np.ascontiguousarray(scene["obj_kind"], dtype=np.uint8),
+        "tri_pos": _f32(scene["tri_pos"], (-1, 9)),
+        "tri_nrm": _f32(scene["tri_nrm"], (-1, 9)),
+        "tri_cull": np.ascontiguousarray(scene["tri_cull"], dtype=np.uint8),
+        "tri_material": np.ascontiguousarray(scene["tri_material"], dtype=np.uint32),
+        "sph": _f32(scene["sph"], (-1, 4)),
+        "sph_material": np.ascontiguousarray(scene["sph_material"], dtype=np.uint32),
+        "materials": np.ascontiguousarray(scene["materials"], dtype=MATERIAL_DTYPE),
+        "light_pos": _f32(scene["light_pos"], (-1, 3)),
+        "light_spectrum": _f32(scene["light_spectrum"], (-1, 4)),
+    }
+    d = SceneDesc()
+    d.n_objects = len(keep["obj_kind"])
+    d.obj_kind = _ptr(keep["obj_kind"])
+    d.n_triangles = len(keep["tri_pos"])
+    d.tri_pos = _ptr(keep["tri_pos"])
+    d.tri_nrm = _ptr(keep["tri_nrm"])
+    d.tri_cull = _ptr(keep["tri_cull"])
+    d.tri_material = _ptr(keep["tri_material"])
+    d.n_spheres = len(keep["sph"])
+    d.sph = _ptr(keep["sph"])
+    d.sph_material = _ptr(keep["sph_material"])
+    d.n_materials = len(keep["materials"])
+    d.materials = _ptr(keep["materials"])
+    d.n_point_lights = len(keep["light_pos"])
+    d.light_pos = _ptr(keep["light_pos"])
+    d.light_spectrum = _ptr(keep["light_spectrum"])
+    return d, keep
+
+
+def camera_params(cam):
+    p = CameraParams()
+    p.origin[:] = [float(v) for v in cam["origin"]]
+    p.look_at[:] = [float(v) for v in cam["look_at"]]
+    p.up[:] = [float(v) for v in cam["up"]]
+    p.focal_length = cam["focal_length"]
+    p.height = cam["height"]
+    p.aspect_ratio = cam["aspect_ratio"]
+    p.aperture_width = cam.get("aperture_width", 0.0)
+    p.aperture_height = cam.get("aperture_height", 0.0)
+    p.aperture_kind = cam.get("aperture_kind", APERTURE_NONE)
+    p.hex_ratio = cam.get("hex_ratio", 0.0)
+    p.focal_plane_dist = cam.get("focal_plane_dist", 0.0)
+    return p
+
+
+def options(opt):
+    return Options(int(opt["image_width"]), int(opt["image_height"]), int(opt["min_sample_count"]), int(opt["max_sample_count"]),
+                   float(opt["epsilon"]))
+
+
+def pixel_streams(xs, ys, states):
+    s = np.zeros(len(xs), dtype=STREAM_DTYPE)
+    s["x"], s["y"], s["w"], s["h"], s["rng_state"] = xs, ys, 1, 1, states
+    return s
+
+
+class Checker:
+    """One of the two CPU checkers behind a uniform Python interface."""
+
+    def __init__(self, which, ndebug=False):
+        if which == "oracle":
+            path, self.prefix = os.path.join(HERE, "libptoracle.so"), "oracle_"
+        elif which == "ref":
+            path, self.prefix = os.path.join(HERE, "_ref", "libptref_ndebug.so" if ndebug else "libptref.so"), "ref_"
+        else:
+            raise ValueError(which)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.which = which
+        self.lib = C.CDLL(path)
+
+    def _fn(self, name, restype=None):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = restype
+        return f
+
+    # ---- RNG ----
+    def rng_draws(self, seed, n):
+        out = np.empty(n, dtype=np.uint32)
+        self._fn("rng_draws")(C.c_uint64(seed), C.c_uint64(n), C.c_void_p(_ptr(out)))
+        return out
+
+    def rng_state_after(self, seed, n):
+        return self._fn("rng_state_after", C.c_uint64)(C.c_uint64(seed), C.c_uint64(n))
+
+    def uniform_floats(self, seed, a, b, n):
+        out = np.empty(n, dtype=np.float32)
+        self._fn("uniform_floats")(C.c_uint64(seed), C.c_float(a), C.c_float(b), C.c_uint64(n), C.c_void_p(_ptr(out)))
+        return out
+
+    def bernoulli(self, seed, p, n):
+        out = np.empty(n, dtype=np.uint8)
+        st = self._fn("bernoulli", C.c_uint64)(C.c_uint64(seed), C.c_double(p), C.c_uint64(n), C.c_void_p(_ptr(out)))
+        return out, st
+
+    # ---- primitives ----
+    def aabb_intersect(self, boxes, rays):
+        boxes, rays = _f32(boxes, (-1, 6)), _f32(rays, (-1, 6))
+        out = np.empty(len(rays), dtype=np.float32)
+        self._fn("aabb_intersect")(C.c_uint64(len(rays)), C.c_void_p(_ptr(boxes)), C.c_void_p(_ptr(rays)), C.c_void_p(_ptr(out)))
+        return out
+
+    def tri_intersect(self, tri, cull, rays):
+        tri, rays = _f32(tri, (-1, 9)), _f32(rays, (-1, 6))
+        cull = np.ascontiguousarray(cull, dtype=np.uint8)
+        out = np.empty(len(rays), dtype=np.float32)
+        self._fn("tri_intersect")(C.c_uint64(len(rays)), C.c_void_p(_ptr(tri)), C.c_void_p(_ptr(cull)), C.c_void_p(_ptr(rays)),
+                                  C.c_void_p(_ptr(out)))
+        return out
+
+    def tri_normal(self, tri, nrm, pos):
+        tri, nrm, pos = _f32(tri, (-1, 9)), _f32(nrm, (-1, 9)), _f32(pos, (-1, 3))
+        out = np.empty((len(pos), 3), dtype=np.float32)
+        self._fn("tri_normal")(C.c_uint64(len(pos)), C.c_void_p(_ptr(tri)), C.c_void_p(_ptr(nrm)), C.c_void_p(_ptr(pos)),
+                               C.c_void_p(_ptr(out)))
+        return out
+
+    def tri_props(self, tri):
+        tri = _f32(tri, (-1, 9))
+        n = len(tri)
+        area, box, fn = np.empty(n, np.float32), np.empty((n, 6), np.float32), np.empty((n, 3), np.float32)
+        self._fn("tri_props")(C.c_uint64(n), C.c_void_p(_ptr(tri)), C.c_void_p(_ptr(area)), C.c_void_p(_ptr(box)), C.c_void_p(_ptr(fn)))
+        return area, box, fn
+
+    def tri_sample(self, tri, cull, states):
+        tri = _f32(tri, (-1, 9))
+        cull = np.ascontiguousarray(cull, dtype=np.uint8)
+        states = np.ascontiguousarray(states, dtype=np.uint64)
+        n = len(tri)
+        pos, p, oc, st = np.empty((n, 3), np.float32), np.empty(n, np.float32), np.empty(n, np.uint8), np.empty(n, np.uint64)
+        self._fn("tri_sample")(C.c_uint64(n), C.c_void_p(_ptr(tri)), C.c_void_p(_ptr(cull)), C.c_void_p(_ptr(states)), C.c_void_p(_ptr(pos)),
+                               C.c_void_p(_ptr(p)), C.c_void_p(_ptr(oc)), C.c_void_p(_ptr(st)))
+        return pos, p, oc, st
+
+    def sphere_intersect(self, sph, rays):
+        sph, rays = _f32(sph, (-1, 4)), _f32(rays, (-1, 6))
+        out = np.empty(len(rays), dtype=np.float32)
+        self._fn("sphere_intersect")(C.c_uint64(len(rays)), C.c_void_p(_ptr(sph)), C.c_void_p(_ptr(rays)), C.c_void_p(_ptr(out)))
+        return out
+
+    def sphere_normal(self, sph, pos):
+        sph, pos = _f32(sph, (-1, 4)), _f32(pos, (-1, 3))
+        out = np.empty((len(pos), 3), dtype=np.float32)
+        self._fn("sphere_normal")(C.c_uint64(len(pos)), C.c_void_p(_ptr(sph)), C.c_void_p(_ptr(pos)), C.c_void_p(_ptr(out)))
+        return out
+
+    def sphere_props(self, sph):
+        sph = _f32(sph, (-1, 4))
+        area, box = np.empty(len(sph), np.float32), np.empty((len(sph), 6), np.float32)
+        self._fn("sphere_props")(C.c_uint64(len(sph)), C.c_void_p(_ptr(sph)), C.c_void_p(_ptr(area)), C.c_void_p(_ptr(box)))
+        return area, box
+
+    def sphere_sample(self, sph, states):
+        sph = _f32(sph, (-1, 4))
+        states = np.ascontiguousarray(states, dtype=np.uint64)
+        n = len(sph)
+        pos, p, st = np.empty((n, 3), np.float32), np.empty(n, np.float32), np.empty(n, np.uint64)
+        self._fn("sphere_sample")(C.c_uint64(n), C.c_void_p(_ptr(sph)), C.c_void_p(_ptr(states)), C.c_void_p(_ptr(pos)), C.c_void_p(_ptr(p)),
+                                  C.c_void_p(_ptr(st)))
+        return pos, p, st
+
+    # ---- BSDF ----
+    def bsdf_propagate(self, kind, one_way, rays, pos, nrm, epsilon, ior, states):
+        rays, pos, nrm, ior = _f32(rays, (-1, 6)), _f32(pos, (-1, 3)), _f32(nrm, (-1, 3)), _f32(ior)
+        states = np.ascontiguousarray(states, dtype=np.uint64)
+        n = len(rays)
+        out_ray, fac, pd, st = np.empty((n, 6), np.float32), np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.uint64)
+        self._fn("bsdf_propagate")(C.c_int(kind), C.c_int(one_way), C.c_uint64(n), C.c_void_p(_ptr(rays)), C.c_void_p(_ptr(pos)),
+                                   C.c_void_p(_ptr(nrm)), C.c_float(epsilon), C.c_void_p(_ptr(ior)), C.c_void_p(_ptr(states)),
+                                   C.c_void_p(_ptr(out_ray)), C.c_void_p(_ptr(fac)), C.c_void_p(_ptr(pd)), C.c_void_p(_ptr(st)))
+        return out_ray, fac, pd, st
+
+    def bsdf_spectrum(self, kind, one_way, from_dir, to_dir, nrm, light, diffuse, specular, synthetic):
+        from_dir, to_dir, nrm = _f32(from_dir, (-1, 3)), _f32(to_dir, (-1, 3)), _f32(nrm, (-1, 3))
+        light, diffuse, specular = _f32(light, (-1, 4)), _f32(diffuse, (-1, 4)), _f32(specular, (-1, 4))
+        n = len(from_dir)
+        rgba, shade, p = np.empty((n, 4), np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
+        self._fn("bsdf_spectrum")(C.c_int(kind), C.c_int(one_way), C.c_uint64(n), C.c_void_p(_ptr(from_dir)), C.c_void_p(_ptr(to_dir)),
+                                  C.c_void_p(_ptr(nrm)), C.c_void_p(_ptr(light)), C.c_void_p(_ptr(diffuse)), C.c_void_p(_ptr(specular)),
+                                  C.c_int(1 if synthetic else 0), C.c_void_p(_ptr(rgba)), C.c_void_p(_ptr(shade)), C.c_void_p(_ptr(p)))
+        return rgba, shade, p
+
+    # ---- camera ----
+    def camera_shoot(self, cam, xy, pixel_width, pixel_height, states):
+        xy = _f32(xy, (-1, 2))
+        states = np.ascontiguousarray(states, dtype=np.uint64)
+        n = len(xy)
+        rays, st = np.empty((n, 6), np.float32), np.empty(n, np.uint64)
+        cp = camera_params(cam)
+        self._fn("camera_shoot")(C.byref(cp), C.c_uint64(n), C.c_void_p(_ptr(xy)), C.c_float(pixel_width), C.c_float(pixel_height),
+                                 C.c_void_p(_ptr(states)), C.c_void_p(_ptr(rays)), C.c_void_p(_ptr(st)))
+        return rays, st
+
+    # ---- scene ----
+    def scene_create(self, scene):
+        d, keep = scene_desc(scene)
+        h = self._fn("scene_create", C.c_void_p)(C.byref(d))
+        return SceneHandle(self, h, scene)
+
+    def bvh_dump(self, scene):
+        d, keep = scene_desc(scene)
+        n = max(2 * d.n_objects - 1, 1)
+        obj, box = np.empty(n, np.int32), np.empty((n, 6), np.float32)
+        cnt = self._fn("bvh_dump", C.c_uint64)(C.byref(d), C.c_void_p(_ptr(obj)), C.c_void_p(_ptr(box)))
+        return obj[:cnt], box[:cnt]
+
+
+class SceneHandle:
+    def __init__(self, checker, handle, scene):
+        self.c, self.h, self.scene = checker, C.c_void_p(handle), scene
+
+    def close(self):
+        if self.h:
+            self.c._fn("scene_destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def intersect(self, rays):
+        rays = _f32(rays, (-1, 6))
+        t, obj = np.empty(len(rays), np.float32), np.empty(len(rays), np.int32)
+        self.c._fn("scene_intersect")(self.h, C.c_uint64(len(rays)), C.c_void_p(_ptr(rays)), C.c_void_p(_ptr(t)), C.c_void_p(_ptr(obj)))
+        return t, obj
+
+    def sample_lights(self, pos, states, max_lights=16):
+        pos = _f32(pos, (-1, 3))
+        states = np.ascontiguousarray(states, dtype=np.uint64)
+        n = len(pos)
+        cnt = np.empty(n, np.int32)
+        lp, rgba, pd = np.zeros((n, max_lights, 3), np.float32), np.zeros((n, max_lights, 4), np.float32), np.zeros((n, max_lights), np.float32)
+        st = np.empty(n, np.uint64)
+        self.c._fn("scene_sample_lights")(self.h, C.c_uint64(n), C.c_void_p(_ptr(pos)), C.c_void_p(_ptr(states)), C.c_int(max_lights),
+                                          C.c_void_p(_ptr(cnt)), C.c_void_p(_ptr(lp)), C.c_void_p(_ptr(rgba)), C.c_void_p(_ptr(pd)),
+                                          C.c_void_p(_ptr(st)))
+        return cnt, lp, rgba, pd, st
+
+    def get_sample(self, cam, opt, xy_camera, states):
+        xy = _f32(xy_camera, (-1, 2))
+        states = np.ascontiguousarray(states, dtype=np.uint64)
+        n = len(xy)
+        rgba, col, st = np.empty((n, 4), np.float32), np.empty(n, np.uint8), np.empty(n, np.uint64)
+        cp, op = camera_params(cam), options(opt)
+        self.c._fn("get_sample")(self.h, C.byref(cp), C.byref(op), C.c_uint64(n), C.c_void_p(_ptr(xy)), C.c_void_p(_ptr(states)),
+                                 C.c_void_p(_ptr(rgba)), C.c_void_p(_ptr(col)), C.c_void_p(_ptr(st)))
+        return rgba, col, st
+
+    def render_streams(self, cam, opt, streams, n_threads=1, image=None):
+        streams = np.ascontiguousarray(streams, dtype=STREAM_DTYPE)
+        if image is None:
+            image = np.zeros((opt["image_height"], opt["image_width"], 4), np.float32)
+        st = np.empty(len(streams), np.uint64)
+        cp, op = camera_params(cam), options(opt)
+        self.c._fn("render_streams")(self.h, C.byref(cp), C.byref(op), C.c_void_p(_ptr(streams)), C.c_uint64(len(streams)),
+                                     C.c_void_p(_ptr(image)), C.c_void_p(_ptr(st)), C.c_int(n_threads))
+        return image, st
+
+    def counters_reset(self):
+        self.c._fn("counters_reset")(self.h)
+
+    def counters(self):
+        c = Counters()
+        self.c._fn("counters_get")(self.h, C.byref(c))
+        return {k: int(getattr(c, k)) for k, _ in Counters._fields_}

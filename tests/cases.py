@@ -1,0 +1,65 @@
+"""Inputs shared by the golden-vector generator and the parity tests: cameras and the scene set.
+
+The scenes are rebuilt from cpupathtrace_amd.scenes (float32 arithmetic only) plus the stored mesh of
+tests/golden/mesh10k.npz, so the generator (build container) and the tests (anywhere) see identical arrays.
+"""
+import os
+
+import numpy as np
+
+from cpupathtrace_amd import scenes
+
+F = np.float32
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def golden_mesh():
+    g = golden("mesh10k")
+    return g["pos"], g["nrm"]
+
+
+def opt_from(arr, epsilon=1e-3):
+    w, h, mn, mx = (int(v) for v in arr)
+    return scenes.options(w, h, mn, mx, epsilon)
+
+
+CAMERAS = {
+    "pinhole": scenes.camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, -1.0),
+    "thinlens_circular": scenes.camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, -1.0, 0.05, 0.05, scenes.APERTURE_CIRCULAR, 0.0, 3.5),
+    "thinlens_hex": scenes.camera((0.3, 0.2, -2.5), (0, 0.1, 0), (0.1, 1, 0), 0.8, 1.2, 1.6, 0.07, 0.03, scenes.APERTURE_HEXAGONAL, 0.4, 2.5),
+    "aperture_no_lens": scenes.camera((0, 0, 0), (0, 0, 1), (0, 1, 0), 0.2, 0.5, 1.94, 0.02, 0.02, scenes.APERTURE_CIRCULAR, 0.0, 0.0),
+}
+
+
+
+def scene_set(mesh):
+    """name -> (scene, camera, options, epsilon-size hints)"""
+    mpos, mnrm = mesh
+    box, box_cam = scenes.box_scene()
+    cornell, cornell_cam = scenes.cornell_scene(256, 256)
+    adv, adv_cam = scenes.advanced_scene()
+    simple, simple_cam = scenes.simple_scene()
+    dbox, dbox_cam = scenes.dragon_box_scene(mpos, mnrm)
+    cmesh, cmesh_cam = scenes.cornell_scene(256, 256, *demo_mesh(mesh))
+    return {
+        "box": (box, box_cam),
+        "cornell": (cornell, cornell_cam),
+        "advanced": (adv, adv_cam),
+        "simple": (simple, simple_cam),
+        "meshbox": (dbox, dbox_cam),
+        "cornellmesh": (cmesh, cmesh_cam),
+    }
+
+
+def demo_mesh(mesh):
+    # the demo places the dragon with a different transform (demo/main.cpp:141-144): half the size, shifted
+    mpos, mnrm = mesh
+    p = mpos.reshape(-1, 3).astype(F)
+    p = (p - np.array([0, -0.5, 0], F)) * F(0.5) + np.array([0.4, -0.8 + 0.25, -0.75], F)
+    return p.reshape(-1, 3, 3).astype(F), mnrm
+
+

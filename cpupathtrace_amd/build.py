@@ -1,0 +1,42 @@
+"""Builds cpupathtrace_amd/libpathtrace_hip.so (HIP kernels + C ABI) for gfx950, in-tree, with hipcc."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpathtrace_hip.so")
+SOURCES = ["pt_api.cpp", "pt_bvh.cpp", "pt_trace.hip", "pt_shade.hip"]
+HEADERS = ["pt_types.h", "pt_kernels.h", "pt_device.h", "pt_libm.h", "pt_bvh.h", os.path.join("..", "..", "include", "pt_hip.h")]
+
+# -ffp-contract=off + correctly rounded divide/sqrt: every fp32/fp64 operation is the IEEE operation the reference's
+# x86-64 build performs (parity is bit-level); -O3 otherwise.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-pthread"]
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    cmd = [hipcc()] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

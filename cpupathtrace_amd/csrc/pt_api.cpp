@@ -1,0 +1,984 @@
+// pt_api.cpp -- host side of libpathtrace_hip.so: the C ABI of include/pt_hip.h.
+//
+// Scene creation flattens the caller's object list into the HBM layout of pt_types.h (building the reference's BVH
+// topology on the way, pt_bvh.cpp); rendering drives the wavefront loop: shade -> trace -> shade -> ... until every stream
+// has rendered all its pixels.  There is no CPU rendering path in this library.
+#include "../../include/pt_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "pt_bvh.h"
+#include "pt_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define PT_HIP(call)                                                                                               \
+    do {                                                                                                           \
+        hipError_t err_ = (call);                                                                                  \
+        if(err_ != hipSuccess) {                                                                                   \
+            return fail(PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err_));                          \
+        }                                                                                                          \
+    } while(0)
+
+int env_int(const char *name, int fallback) {
+    const char *v = std::getenv(name);
+    return (v != nullptr && *v != '\0') ? std::atoi(v) : fallback;
+}
+
+inline float fmin_std(float a, float b) {
+    return (b < a) ? b : a;
+}
+inline float fmax_std(float a, float b) {
+    return (a < b) ? b : a;
+}
+
+struct Vec3 {
+    float x, y, z;
+};
+inline Vec3 sub(Vec3 a, Vec3 b) {
+    return {a.x - b.x, a.y - b.y, a.z - b.z};
+}
+inline Vec3 scale(Vec3 a, float f) {
+    return {a.x * f, a.y * f, a.z * f};
+}
+inline float dot(Vec3 a, Vec3 b) {
+    float d = 0.0F;
+    d += a.x * b.x;
+    d += a.y * b.y;
+    d += a.z * b.z;
+    return d;
+}
+inline Vec3 cross(Vec3 a, Vec3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline Vec3 normalize(Vec3 a) {
+    const float inv = 1.0F / std::sqrt(dot(a, a));
+    return scale(a, inv);
+}
+inline Vec3 ld(const float *p) {
+    return {p[0], p[1], p[2]};
+}
+
+uint32_t bits(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+float from_bits(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+template<typename T>
+struct DevBuf {
+    T *ptr = nullptr;
+    size_t count = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if(ptr != nullptr) {
+            (void)hipFree(ptr);
+            ptr = nullptr;
+            count = 0;
+        }
+    }
+    hipError_t ensure(size_t n) {
+        if(n <= count && ptr != nullptr) {
+            return hipSuccess;
+        }
+        release();
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ptr), bytes);
+        if(e == hipSuccess) {
+            count = std::max<size_t>(n, 1);
+        }
+        return e;
+    }
+    hipError_t upload(const std::vector<T> &host) {
+        hipError_t e = ensure(host.size());
+        if(e != hipSuccess || host.empty()) {
+            return e;
+        }
+        return hipMemcpy(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+struct F4 {
+    float x, y, z, w;
+};
+
+} // namespace
+
+struct pt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int cu_count = 256;
+
+    // host copies kept for introspection and for mapping references back to object indices
+    ptb::Tree tree;
+    std::vector<uint32_t> tri_obj;
+    std::vector<uint32_t> sph_obj;
+    uint32_t n_objects = 0;
+    uint32_t n_emissive = 0;
+
+    // device scene
+    DevBuf<F4> pairs, tris, tri_nrm, spheres, materials, lights, emis;
+    DevBuf<uint2> sph_meta;
+    DevBuf<float> emis_cdf;
+    PtDevScene dev{};
+
+    // render workspace (grown on demand, reused between calls)
+    uint32_t ws_slots = 0;
+    DevBuf<int4> rect;
+    DevBuf<uint64_t> rng;
+    DevBuf<int32_t> cursor, path_length;
+    DevBuf<uint32_t> flags, nee_mask, vis;
+    DevBuf<F4> ray_o, ray_d, spectrum, out, nee;
+    DevBuf<double> divisor, bounce_pd;
+    DevBuf<PtEstimator> est;
+    DevBuf<PtCandidate> cand;
+    DevBuf<uint2> hit;
+    DevBuf<F4> q_ray_o, q_ray_d;
+    DevBuf<uint32_t> q_header; // count[8], head[8]
+    DevBuf<uint2> spill;
+    DevBuf<PtDevCounters> counters;
+    DevBuf<F4> image;
+    DevBuf<int4> tiles;
+    DevBuf<uint32_t> tile_offset;
+    DevBuf<float> batch_rays;
+    uint32_t shard_capacity = 0;
+    PtTraceConfig trace_cfg{};
+    PtDevCounters *host_counters = nullptr; // pinned
+
+    ~pt_scene() {
+        if(host_counters != nullptr) {
+            (void)hipHostFree(host_counters);
+        }
+        if(stream != nullptr) {
+            (void)hipStreamDestroy(stream);
+        }
+    }
+};
+
+namespace {
+
+int device_count_quiet() {
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+PtPaths make_paths(pt_scene *s, uint32_t n) {
+    PtPaths P{};
+    P.n = n;
+    P.rect = s->rect.ptr;
+    P.rng = s->rng.ptr;
+    P.cursor = s->cursor.ptr;
+    P.flags = s->flags.ptr;
+    P.ray_o = reinterpret_cast<float4 *>(s->ray_o.ptr);
+    P.ray_d = reinterpret_cast<float4 *>(s->ray_d.ptr);
+    P.spectrum = reinterpret_cast<float4 *>(s->spectrum.ptr);
+    P.out = reinterpret_cast<float4 *>(s->out.ptr);
+    P.divisor = s->divisor.ptr;
+    P.bounce_pd = s->bounce_pd.ptr;
+    P.path_length = s->path_length.ptr;
+    P.nee = reinterpret_cast<float4 *>(s->nee.ptr);
+    P.nee_mask = s->nee_mask.ptr;
+    P.est = s->est.ptr;
+    P.cand = s->cand.ptr;
+    P.hit = s->hit.ptr;
+    P.vis = s->vis.ptr;
+    return P;
+}
+
+PtQueue make_queue(pt_scene *s) {
+    PtQueue q{};
+    q.ray_o = reinterpret_cast<float4 *>(s->q_ray_o.ptr);
+    q.ray_d = reinterpret_cast<float4 *>(s->q_ray_d.ptr);
+    q.count = s->q_header.ptr;
+    q.head = s->q_header.ptr + PT_SHARDS;
+    q.shard_capacity = s->shard_capacity;
+    return q;
+}
+
+// workspace for n stream slots and a queue of `queue_rays_per_slot` rays per slot
+int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot) {
+    const uint32_t blocks = (n + 255) / 256;
+    const uint32_t blocks_per_shard = (blocks + PT_SHARDS - 1) / PT_SHARDS;
+    const uint32_t cap = std::max<uint32_t>(blocks_per_shard * 256U * rays_per_slot, 256U);
+    PT_HIP(s->rect.ensure(n));
+    PT_HIP(s->rng.ensure(n));
+    PT_HIP(s->cursor.ensure(n));
+    PT_HIP(s->path_length.ensure(n));
+    PT_HIP(s->flags.ensure(n));
+    PT_HIP(s->nee_mask.ensure(n));
+    PT_HIP(s->vis.ensure(static_cast<size_t>(n) * PT_MAX_NEE));
+    PT_HIP(s->ray_o.ensure(n));
+    PT_HIP(s->ray_d.ensure(n));
+    PT_HIP(s->spectrum.ensure(n));
+    PT_HIP(s->out.ensure(n));
+    PT_HIP(s->nee.ensure(static_cast<size_t>(n) * PT_MAX_NEE));
+    PT_HIP(s->divisor.ensure(n));
+    PT_HIP(s->bounce_pd.ensure(n));
+    PT_HIP(s->est.ensure(n));
+    PT_HIP(s->cand.ensure(static_cast<size_t>(n) * PT_MAX_CANDIDATES));
+    PT_HIP(s->hit.ensure(n));
+    PT_HIP(s->q_ray_o.ensure(static_cast<size_t>(cap) * PT_SHARDS));
+    PT_HIP(s->q_ray_d.ensure(static_cast<size_t>(cap) * PT_SHARDS));
+    PT_HIP(s->q_header.ensure(2 * PT_SHARDS));
+    PT_HIP(s->counters.ensure(1));
+    s->shard_capacity = static_cast<uint32_t>(s->q_ray_o.count / PT_SHARDS);
+    s->ws_slots = n;
+    if(s->host_counters == nullptr) {
+        PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->host_counters), sizeof(PtDevCounters), hipHostMallocDefault));
+    }
+    return PT_OK;
+}
+
+int setup_trace(pt_scene *s) {
+    PtTraceConfig &cfg = s->trace_cfg;
+    if(cfg.grid != 0) {
+        return PT_OK;
+    }
+    int stack_lds = env_int("PT_STACK_LDS", 16);
+    if(stack_lds != 8 && stack_lds != 16 && stack_lds != 24) {
+        stack_lds = 16;
+    }
+    cfg.stack_lds = stack_lds;
+    cfg.lds_bytes = static_cast<size_t>(stack_lds) * 256 * sizeof(uint2) + static_cast<size_t>(s->dev.n_lds_pairs) * 64 + static_cast<size_t>(s->dev.n_lds_tris) * 48;
+    const int per_cu = pt_trace_blocks_per_cu(stack_lds, cfg.lds_bytes);
+    const int limit = env_int("PT_TRACE_BLOCKS_PER_CU", 0);
+    cfg.grid = s->cu_count * ((limit > 0 && limit < per_cu) ? limit : per_cu);
+    cfg.spill_depth = s->tree.depth > static_cast<uint32_t>(stack_lds) ? s->tree.depth - static_cast<uint32_t>(stack_lds) : 1U;
+    PT_HIP(s->spill.ensure(static_cast<size_t>(cfg.grid) * 256 * cfg.spill_depth));
+    cfg.spill = s->spill.ptr;
+    return PT_OK;
+}
+
+PtDevCamera derive_camera(const pt_camera_params *c) {
+    // Camera::Camera, src/camera.cpp:53-76
+    PtDevCamera cam{};
+    const Vec3 origin = ld(c->origin);
+    const Vec3 forward_dir = normalize(sub(ld(c->look_at), origin));
+    const Vec3 forward = scale(forward_dir, c->focal_length);
+    const Vec3 up_dir = normalize(ld(c->up));
+    const float height_half = c->height / 2.0F;
+    const Vec3 up = scale(up_dir, height_half);
+    const Vec3 right_dir = normalize(cross(forward, up));
+    const float width_half = height_half * c->aspect_ratio;
+    const Vec3 right = scale(right_dir, width_half);
+    const Vec3 v[4] = {origin, forward, up, right};
+    float *dst[4] = {cam.origin, cam.forward, cam.up, cam.right};
+    for(int i = 0; i < 4; i++) {
+        dst[i][0] = v[i].x;
+        dst[i][1] = v[i].y;
+        dst[i][2] = v[i].z;
+    }
+    cam.aperture_width_half = c->aperture_width / 2.0F;
+    cam.aperture_height_half = c->aperture_height / 2.0F;
+    cam.aperture_kind = c->aperture_kind;
+    cam.hex_ratio = fmin_std(fmax_std(c->hex_ratio, 0.0F), 1.0F); // camera.cpp:22-24
+    cam.focal_plane_dist = c->focal_plane_dist;
+    return cam;
+}
+
+int derive_options(const pt_options *o, PtDevOptions *out) {
+    PtDevOptions d{};
+    d.image_width = o->image_width;
+    d.image_height = o->image_height;
+    d.min_sample_count = o->min_sample_count;
+    d.max_sample_count = o->max_sample_count;
+    d.epsilon = o->epsilon;
+    d.pixel_width = 1.0F / static_cast<float>(o->image_width);
+    d.pixel_height = 1.0F / static_cast<float>(o->image_height);
+    // worker.cpp:158-164
+    d.stats_sample_count = std::min(std::max(o->min_sample_count / 4, 1), 64);
+    d.candidate_batch_count = std::max(std::max(o->min_sample_count, o->max_sample_count / 4) / d.stats_sample_count, 2);
+    d.check_sample_count =
+      std::min(std::max({o->min_sample_count / 2, (o->max_sample_count - o->min_sample_count) / 8, 8, d.stats_sample_count}), 1024) / d.stats_sample_count;
+    // closed candidates a pixel can accumulate (worker.cpp:214-222)
+    const int batches = std::max(o->max_sample_count, 0) / d.stats_sample_count;
+    const int closed = batches > 0 ? (batches - 1) / d.candidate_batch_count : 0;
+    if(closed > PT_MAX_CANDIDATES) {
+        return fail(PT_ERR_UNSUPPORTED, "sample counts give more than 8 estimator candidates per pixel");
+    }
+    *out = d;
+    return PT_OK;
+}
+
+int check_render_args(pt_scene *scene, const pt_camera_params *camera, const pt_options *options) {
+    if(scene == nullptr || camera == nullptr || options == nullptr) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    if(options->image_width <= 0 || options->image_height <= 0) {
+        return fail(PT_ERR_INVALID, "image size must be positive");
+    }
+    return PT_OK;
+}
+
+// The wavefront loop over an initialised set of `n` stream slots.
+int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, uint32_t n, float4 *d_image, pt_stats *stats) {
+    PtPaths P = make_paths(s, n);
+    PtQueue q = make_queue(s);
+    hipStream_t st = s->stream;
+    PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters), st));
+
+    const bool timing = stats != nullptr;
+    const int kEventPairs = 64;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    if(timing) {
+        ev.resize(4 * kEventPairs);
+        for(auto &e : ev) {
+            PT_HIP(hipEventCreate(&e));
+        }
+        PT_HIP(hipEventCreate(&ev_begin));
+        PT_HIP(hipEventCreate(&ev_end));
+        PT_HIP(hipEventRecord(ev_begin, st));
+    }
+    double trace_ms = 0.0, shade_ms = 0.0;
+    auto drain_events = [&](int used) -> int {
+        for(int i = 0; i < used; i++) {
+            float a = 0.0F, b = 0.0F;
+            PT_HIP(hipEventSynchronize(ev[4 * i + 3]));
+            PT_HIP(hipEventElapsedTime(&a, ev[4 * i + 0], ev[4 * i + 1]));
+            PT_HIP(hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3]));
+            shade_ms += a;
+            trace_ms += b;
+        }
+        return PT_OK;
+    };
+
+    const int check_every = n <= 65536 ? 4 : 16;
+    uint64_t iterations = 0;
+    int pending = 0;
+    for(;;) {
+        for(int k = 0; k < check_every; k++) {
+            PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, 2 * PT_SHARDS * sizeof(uint32_t), st));
+            if(timing) {
+                PT_HIP(hipEventRecord(ev[4 * pending + 0], st));
+            }
+            pt_launch_shade(st, s->dev, cam, opt, P, q, d_image, s->counters.ptr);
+            if(timing) {
+                PT_HIP(hipEventRecord(ev[4 * pending + 1], st));
+                PT_HIP(hipEventRecord(ev[4 * pending + 2], st));
+            }
+            pt_launch_trace(st, s->dev, q, P, s->trace_cfg, s->counters.ptr);
+            if(timing) {
+                PT_HIP(hipEventRecord(ev[4 * pending + 3], st));
+                if(++pending == kEventPairs) {
+                    int rc = drain_events(pending);
+                    if(rc != PT_OK) {
+                        return rc;
+                    }
+                    pending = 0;
+                }
+            }
+            iterations++;
+        }
+        PT_HIP(hipMemcpyAsync(s->host_counters, s->counters.ptr, sizeof(PtDevCounters), hipMemcpyDeviceToHost, st));
+        PT_HIP(hipStreamSynchronize(st));
+        PT_HIP(hipGetLastError());
+        if(s->host_counters->streams_done >= n) {
+            break;
+        }
+        if(iterations > (1ULL << 40)) {
+            return fail(PT_ERR_HIP, "wavefront loop did not terminate");
+        }
+    }
+    if(timing) {
+        int rc = drain_events(pending);
+        if(rc != PT_OK) {
+            return rc;
+        }
+        PT_HIP(hipEventRecord(ev_end, st));
+        PT_HIP(hipEventSynchronize(ev_end));
+        float total = 0.0F;
+        PT_HIP(hipEventElapsedTime(&total, ev_begin, ev_end));
+        const PtDevCounters &c = *s->host_counters;
+        stats->samples = c.samples;
+        stats->rays_traced = c.rays;
+        stats->shadow_rays_traced = c.shadow_rays;
+        stats->node_visits = c.node_visits;
+        stats->leaf_tests = c.leaf_tests;
+        stats->vertices = c.vertices;
+        stats->iterations = iterations;
+        stats->trace_ms = trace_ms;
+        stats->shade_ms = shade_ms;
+        stats->total_ms = total;
+        for(auto &e : ev) {
+            (void)hipEventDestroy(e);
+        }
+        (void)hipEventDestroy(ev_begin);
+        (void)hipEventDestroy(ev_end);
+    }
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pt_device_count(void) {
+    return device_count_quiet();
+}
+
+const char *pt_last_error(void) {
+    return g_last_error.c_str();
+}
+
+uint64_t pt_pixel_seed(uint64_t base_seed, int32_t x, int32_t y) {
+    return pt_host_pixel_seed(base_seed, x, y);
+}
+
+uint64_t pt_rng_seed_to_state(uint64_t seed) {
+    return seed ^ (~seed << 32);
+}
+
+size_t pt_job_tiles(int32_t image_width, int32_t image_height, pt_tile *out, size_t capacity) {
+    // processJob, src/worker.cpp:389-414
+    const int width = std::max(image_width, 0);
+    const int height = std::max(image_height, 0);
+    if(width == 0 || height == 0) {
+        return 0;
+    }
+    const int tile_size = std::max(std::min(std::min(width, height) / 4, 32), 1);
+    const int horizontal_tiles = (width + (tile_size - 1)) / tile_size;
+    const int vertical_tiles = (height + (tile_size - 1)) / tile_size;
+    size_t n = 0;
+    for(int ty = 0; ty < vertical_tiles; ty++) {
+        for(int tx = 0; tx < horizontal_tiles; tx++) {
+            if(out != nullptr && n < capacity) {
+                const int ox = tx * tile_size, oy = ty * tile_size;
+                out[n] = pt_tile{ox, oy, std::min(width - ox, tile_size), std::min(height - oy, tile_size)};
+            }
+            n++;
+        }
+    }
+    return n;
+}
+
+int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
+    if(d == nullptr || out == nullptr) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    *out = nullptr;
+    const int n_dev = device_count_quiet();
+    if(n_dev <= 0) {
+        return fail(PT_ERR_NO_DEVICE, "no HIP device available; libpathtrace_hip has no CPU path");
+    }
+    if(device < 0 || device >= n_dev) {
+        return fail(PT_ERR_NO_DEVICE, "device index out of range");
+    }
+    if(d->n_objects != d->n_triangles + d->n_spheres) {
+        return fail(PT_ERR_INVALID, "n_objects must equal n_triangles + n_spheres");
+    }
+    if((d->n_objects > 0 && d->obj_kind == nullptr) || (d->n_triangles > 0 && (d->tri_pos == nullptr || d->tri_cull == nullptr || d->tri_material == nullptr)) ||
+       (d->n_spheres > 0 && (d->sph == nullptr || d->sph_material == nullptr)) || (d->n_materials > 0 && d->materials == nullptr) ||
+       (d->n_point_lights > 0 && (d->light_pos == nullptr || d->light_spectrum == nullptr))) {
+        return fail(PT_ERR_INVALID, "missing array in scene description");
+    }
+    if(d->n_triangles > PT_REF_INDEX || d->n_spheres > PT_REF_INDEX) {
+        return fail(PT_ERR_UNSUPPORTED, "too many objects");
+    }
+
+    std::unique_ptr<pt_scene> s(new pt_scene());
+    s->device = device;
+    PT_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PT_HIP(hipGetDeviceProperties(&prop, device));
+    s->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    PT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->n_objects = d->n_objects;
+
+    // ---- leaves: bounding volume and reference word per object, in construction order --------------------------------
+    std::vector<ptb::Box> boxes(d->n_objects);
+    std::vector<uint32_t> leaf_ref(d->n_objects);
+    s->tri_obj.resize(d->n_triangles);
+    s->sph_obj.resize(d->n_spheres);
+    {
+        uint32_t ti = 0, si = 0;
+        for(uint32_t i = 0; i < d->n_objects; i++) {
+            ptb::Box &b = boxes[i];
+            if(d->obj_kind[i] == PT_OBJ_TRIANGLE) {
+                if(ti >= d->n_triangles) {
+                    return fail(PT_ERR_INVALID, "obj_kind lists more triangles than n_triangles");
+                }
+                const float *p = d->tri_pos + 9 * static_cast<size_t>(ti);
+                for(int k = 0; k < 3; k++) { // Triangle::getBoundingVolume, object.cpp:184-186
+                    b.lo[k] = fmin_std(fmin_std(p[k], p[3 + k]), p[6 + k]);
+                    b.hi[k] = fmax_std(fmax_std(p[k], p[3 + k]), p[6 + k]);
+                }
+                leaf_ref[i] = PT_REF_LEAF | ti;
+                s->tri_obj[ti] = i;
+                if(d->tri_material[ti] != PT_NO_MATERIAL && d->tri_material[ti] >= d->n_materials) {
+                    return fail(PT_ERR_INVALID, "triangle material index out of range");
+                }
+                ti++;
+            }
+            else if(d->obj_kind[i] == PT_OBJ_SPHERE) {
+                if(si >= d->n_spheres) {
+                    return fail(PT_ERR_INVALID, "obj_kind lists more spheres than n_spheres");
+                }
+                const float *sp = d->sph + 4 * static_cast<size_t>(si);
+                for(int k = 0; k < 3; k++) { // Sphere::getBoundingVolume, object.cpp:90-93
+                    b.lo[k] = sp[k] - sp[3];
+                    b.hi[k] = sp[k] + sp[3];
+                }
+                leaf_ref[i] = PT_REF_LEAF | PT_REF_SPHERE | si;
+                s->sph_obj[si] = i;
+                if(d->sph_material[si] != PT_NO_MATERIAL && d->sph_material[si] >= d->n_materials) {
+                    return fail(PT_ERR_INVALID, "sphere material index out of range");
+                }
+                si++;
+            }
+            else {
+                return fail(PT_ERR_INVALID, "unknown object kind");
+            }
+        }
+    }
+
+    // ---- BVH -------------------------------------------------------------------------------------------------------------
+    int threads = env_int("PT_BUILD_THREADS", static_cast<int>(std::thread::hardware_concurrency()));
+    threads = std::max(1, std::min(threads, 64));
+    s->tree = ptb::build_reference_bvh(boxes, threads);
+    if(s->tree.depth > PT_MAX_DEPTH) {
+        return fail(PT_ERR_UNSUPPORTED, "BVH deeper than 128 levels");
+    }
+    ptb::FlatBvh flat = ptb::flatten_breadth_first(s->tree, leaf_ref);
+
+    // ---- triangle / sphere / material records --------------------------------------------------------------------------------
+    std::vector<F4> tris(3 * static_cast<size_t>(d->n_triangles)), nrm(3 * static_cast<size_t>(d->n_triangles));
+    for(uint32_t t = 0; t < d->n_triangles; t++) {
+        const float *p = d->tri_pos + 9 * static_cast<size_t>(t);
+        const Vec3 a = ld(p), b = ld(p + 3), c = ld(p + 6);
+        const Vec3 ab = sub(b, a), ac = sub(c, a);
+        const uint32_t obj_cull = s->tri_obj[t] | (d->tri_cull[t] != 0 ? 0x80000000U : 0U);
+        tris[3 * static_cast<size_t>(t) + 0] = {a.x, a.y, a.z, ab.x};
+        tris[3 * static_cast<size_t>(t) + 1] = {ab.y, ab.z, ac.x, ac.y};
+        tris[3 * static_cast<size_t>(t) + 2] = {ac.z, from_bits(d->tri_material[t]), from_bits(obj_cull), 0.0F};
+        Vec3 na, nb, nc;
+        if(d->tri_nrm != nullptr) {
+            const float *q = d->tri_nrm + 9 * static_cast<size_t>(t);
+            na = ld(q);
+            nb = ld(q + 3);
+            nc = ld(q + 6);
+        }
+        else {
+            na = nb = nc = normalize(cross(ab, ac)); // Triangle::Triangle, object.cpp:118-124
+        }
+        nrm[3 * static_cast<size_t>(t) + 0] = {na.x, na.y, na.z, nb.x};
+        nrm[3 * static_cast<size_t>(t) + 1] = {nb.y, nb.z, nc.x, nc.y};
+        nrm[3 * static_cast<size_t>(t) + 2] = {nc.z, 0.0F, 0.0F, 0.0F};
+    }
+    std::vector<F4> spheres(d->n_spheres);
+    std::vector<uint2> sph_meta(d->n_spheres);
+    for(uint32_t i = 0; i < d->n_spheres; i++) {
+        const float *sp = d->sph + 4 * static_cast<size_t>(i);
+        spheres[i] = {sp[0], sp[1], sp[2], sp[3]};
+        sph_meta[i] = make_uint2(d->sph_material[i], s->sph_obj[i]);
+    }
+    std::vector<F4> materials(4 * static_cast<size_t>(d->n_materials));
+    for(uint32_t i = 0; i < d->n_materials; i++) {
+        const pt_material &m = d->materials[i];
+        materials[4 * static_cast<size_t>(i) + 0] = {m.diffuse[0], m.diffuse[1], m.diffuse[2], m.diffuse[3]};
+        materials[4 * static_cast<size_t>(i) + 1] = {m.specular[0], m.specular[1], m.specular[2], m.specular[3]};
+        materials[4 * static_cast<size_t>(i) + 2] = {m.emission[0], m.emission[1], m.emission[2], m.emission[3]};
+        materials[4 * static_cast<size_t>(i) + 3] = {m.ior, from_bits(static_cast<uint32_t>(m.bsdf)), from_bits(static_cast<uint32_t>(m.one_way != 0)), 0.0F};
+        if(m.bsdf < PT_BSDF_LAMBERTIAN || m.bsdf > PT_BSDF_MIRROR) {
+            return fail(PT_ERR_INVALID, "unknown BSDF kind");
+        }
+    }
+    std::vector<F4> lights(2 * static_cast<size_t>(d->n_point_lights));
+    for(uint32_t i = 0; i < d->n_point_lights; i++) {
+        const float *p = d->light_pos + 3 * static_cast<size_t>(i);
+        const float *c = d->light_spectrum + 4 * static_cast<size_t>(i);
+        lights[2 * static_cast<size_t>(i) + 0] = {p[0], p[1], p[2], 0.0F};
+        lights[2 * static_cast<size_t>(i) + 1] = {c[0], c[1], c[2], c[3]};
+    }
+
+    // ---- emissive objects: Scene::registerEmissiveObjects + CDF (scene.cpp:183-208, 167-180) -----------------------------------
+    std::vector<int32_t> dfs;
+    ptb::leaves_depth_first(s->tree, dfs);
+    std::vector<F4> emis;
+    std::vector<float> cdf;
+    const float pi = static_cast<float>(M_PI);
+    for(int32_t obj : dfs) {
+        const uint32_t ref = leaf_ref[obj];
+        const uint32_t idx = ref & PT_REF_INDEX;
+        const bool is_sphere = (ref & PT_REF_SPHERE) != 0;
+        const uint32_t mat = is_sphere ? d->sph_material[idx] : d->tri_material[idx];
+        if(mat == PT_NO_MATERIAL) {
+            continue; // default material has no emission
+        }
+        const float *e = d->materials[mat].emission;
+        const float emissive_power = (e[0] + e[1] + e[2]) * e[3];
+        if(emissive_power <= 0.0F) {
+            continue;
+        }
+        float area;
+        if(is_sphere) {
+            const float r = d->sph[4 * static_cast<size_t>(idx) + 3];
+            area = 4.0F * pi * (r * r); // object.cpp:95-99
+        }
+        else {
+            const float *p = d->tri_pos + 9 * static_cast<size_t>(idx);
+            const Vec3 c = cross(sub(ld(p + 3), ld(p)), sub(ld(p + 6), ld(p)));
+            area = std::sqrt(dot(c, c)) / 2.0F; // object.cpp:188-190
+        }
+        const float object_probability = emissive_power * area;
+        if(object_probability <= 0.0F) {
+            continue;
+        }
+        if(is_sphere) {
+            const float *sp = d->sph + 4 * static_cast<size_t>(idx);
+            emis.push_back({sp[0], sp[1], sp[2], sp[3]});
+            emis.push_back({0.0F, 0.0F, 0.0F, 0.0F});
+            emis.push_back({0.0F, from_bits(ref), 0.0F, from_bits(mat)});
+        }
+        else {
+            const float *p = d->tri_pos + 9 * static_cast<size_t>(idx);
+            emis.push_back({p[0], p[1], p[2], p[3]});
+            emis.push_back({p[4], p[5], p[6], p[7]});
+            emis.push_back({p[8], from_bits(ref), from_bits(d->tri_cull[idx] != 0 ? 1U : 0U), from_bits(mat)});
+        }
+        emis.push_back({e[0], e[1], e[2], e[3]});
+        cdf.push_back(object_probability);
+    }
+    {
+        float cumulative_probability = 0.0F;
+        for(float &v : cdf) {
+            const float probability = v;
+            v += cumulative_probability;
+            cumulative_probability += probability;
+        }
+        for(float &v : cdf) {
+            v /= cumulative_probability;
+        }
+    }
+    s->n_emissive = static_cast<uint32_t>(cdf.size());
+    const int emissive_object_count = static_cast<int>(cdf.size());
+    const int object_sample_count = std::min(2 + static_cast<int>(std::log10(emissive_object_count + 1)), emissive_object_count); // scene.cpp:226
+    if(d->n_point_lights + static_cast<uint32_t>(object_sample_count) > PT_MAX_NEE) {
+        return fail(PT_ERR_UNSUPPORTED, "more than 8 light samples per path vertex");
+    }
+
+    // ---- upload --------------------------------------------------------------------------------------------------------------
+    std::vector<F4> pairs(4 * static_cast<size_t>(flat.n_pairs));
+    std::memcpy(pairs.data(), flat.pairs.data(), flat.pairs.size() * sizeof(float));
+    PT_HIP(s->pairs.upload(pairs));
+    PT_HIP(s->tris.upload(tris));
+    PT_HIP(s->tri_nrm.upload(nrm));
+    PT_HIP(s->spheres.upload(spheres));
+    PT_HIP(s->sph_meta.upload(sph_meta));
+    PT_HIP(s->materials.upload(materials));
+    PT_HIP(s->lights.upload(lights));
+    PT_HIP(s->emis.upload(emis));
+    PT_HIP(s->emis_cdf.upload(cdf));
+
+    PtDevScene &dev = s->dev;
+    dev.pairs = reinterpret_cast<const float4 *>(s->pairs.ptr);
+    dev.tris = reinterpret_cast<const float4 *>(s->tris.ptr);
+    dev.tri_nrm = reinterpret_cast<const float4 *>(s->tri_nrm.ptr);
+    dev.spheres = reinterpret_cast<const float4 *>(s->spheres.ptr);
+    dev.sph_meta = s->sph_meta.ptr;
+    dev.materials = reinterpret_cast<const float4 *>(s->materials.ptr);
+    dev.lights = reinterpret_cast<const float4 *>(s->lights.ptr);
+    dev.emis = reinterpret_cast<const float4 *>(s->emis.ptr);
+    dev.emis_cdf = s->emis_cdf.ptr;
+    for(int k = 0; k < 3; k++) {
+        dev.root_lo[k] = flat.root_box.lo[k];
+        dev.root_hi[k] = flat.root_box.hi[k];
+    }
+    dev.root_ref = flat.root_ref;
+    dev.n_pairs = flat.n_pairs;
+    dev.n_tris = d->n_triangles;
+    dev.n_spheres = d->n_spheres;
+    dev.n_lights = d->n_point_lights;
+    dev.n_emis = s->n_emissive;
+    dev.n_object_samples = static_cast<uint32_t>(object_sample_count);
+    // LDS staging: the breadth-first top of the tree, and the triangle records of small scenes
+    const uint32_t lds_pairs_cap = static_cast<uint32_t>(std::max(env_int("PT_LDS_PAIRS", 255), 0));
+    const uint32_t lds_tris_cap = static_cast<uint32_t>(std::max(env_int("PT_LDS_TRIS", 128), 0));
+    dev.n_lds_pairs = std::min(flat.n_pairs, lds_pairs_cap);
+    dev.n_lds_tris = d->n_triangles <= lds_tris_cap ? d->n_triangles : 0U;
+
+    int rc = setup_trace(s.get());
+    if(rc != PT_OK) {
+        return rc;
+    }
+    *out = s.release();
+    return PT_OK;
+}
+
+void pt_scene_destroy(pt_scene *scene) {
+    if(scene == nullptr) {
+        return;
+    }
+    (void)hipSetDevice(scene->device);
+    if(scene->stream != nullptr) {
+        (void)hipStreamSynchronize(scene->stream);
+    }
+    delete scene;
+}
+
+int pt_scene_info(const pt_scene *scene, uint64_t *n_nodes, uint32_t *depth, uint32_t *n_emissive) {
+    if(scene == nullptr) {
+        return fail(PT_ERR_INVALID, "null scene");
+    }
+    if(n_nodes != nullptr) {
+        *n_nodes = scene->tree.nodes.size();
+    }
+    if(depth != nullptr) {
+        *depth = scene->tree.depth;
+    }
+    if(n_emissive != nullptr) {
+        *n_emissive = scene->n_emissive;
+    }
+    return PT_OK;
+}
+
+int pt_scene_bvh_dump(const pt_scene *scene, int32_t *out_obj, float *out_box, uint64_t capacity, uint64_t *n_written) {
+    if(scene == nullptr || out_obj == nullptr || out_box == nullptr) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    std::vector<int32_t> obj;
+    std::vector<ptb::Box> box;
+    ptb::dump_preorder(scene->tree, obj, box);
+    const uint64_t n = std::min<uint64_t>(obj.size(), capacity);
+    for(uint64_t i = 0; i < n; i++) {
+        out_obj[i] = obj[i];
+        std::memcpy(out_box + 6 * i, &box[i], sizeof(float) * 6);
+    }
+    if(n_written != nullptr) {
+        *n_written = obj.size();
+    }
+    return PT_OK;
+}
+
+int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, int32_t *out_obj) {
+    if(s == nullptr || (n > 0 && (rays == nullptr || out_t == nullptr || out_obj == nullptr))) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    if(n == 0) {
+        return PT_OK;
+    }
+    if(n > 0x7fffffffULL) {
+        return fail(PT_ERR_INVALID, "too many rays in one batch");
+    }
+    PT_HIP(hipSetDevice(s->device));
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    int rc = ensure_workspace(s, std::max(n32, s->ws_slots), 1U + s->dev.n_lights + s->dev.n_object_samples);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    PT_HIP(s->batch_rays.ensure(6 * n));
+    PtPaths P = make_paths(s, n32);
+    PtQueue q = make_queue(s);
+    if(q.shard_capacity < (n32 + PT_SHARDS - 1) / PT_SHARDS) {
+        return fail(PT_ERR_NOMEM, "queue too small for batch");
+    }
+    hipStream_t st = s->stream;
+    PT_HIP(hipMemcpyAsync(s->batch_rays.ptr, rays, 6 * n * sizeof(float), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, 2 * PT_SHARDS * sizeof(uint32_t), st));
+    PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters), st));
+    pt_launch_batch_rays(st, s->batch_rays.ptr, n32, q);
+    pt_launch_trace(st, s->dev, q, P, s->trace_cfg, s->counters.ptr);
+    std::vector<uint2> hits(n);
+    PT_HIP(hipMemcpyAsync(hits.data(), s->hit.ptr, n * sizeof(uint2), hipMemcpyDeviceToHost, st));
+    PT_HIP(hipStreamSynchronize(st));
+    PT_HIP(hipGetLastError());
+    for(size_t i = 0; i < n; i++) {
+        const float t = from_bits(hits[i].x);
+        const uint32_t ref = hits[i].y;
+        out_t[i] = t;
+        if(t < 0.0F || ref == PT_REF_NONE) {
+            out_obj[i] = -1;
+        }
+        else if(ref & PT_REF_SPHERE) {
+            out_obj[i] = static_cast<int32_t>(s->sph_obj[ref & PT_REF_INDEX]);
+        }
+        else {
+            out_obj[i] = static_cast<int32_t>(s->tri_obj[ref & PT_REF_INDEX]);
+        }
+    }
+    return PT_OK;
+}
+
+int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_stream *streams, size_t n, float *out_image,
+                      uint64_t *out_states, pt_stats *stats) {
+    int rc = check_render_args(s, camera, options);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    if(n > 0 && (streams == nullptr || out_image == nullptr)) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    if(stats != nullptr) {
+        std::memset(stats, 0, sizeof(*stats));
+    }
+    if(n == 0) {
+        return PT_OK;
+    }
+    if(n > 0x3fffffffULL) {
+        return fail(PT_ERR_INVALID, "too many streams");
+    }
+    PtDevOptions opt;
+    rc = derive_options(options, &opt);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    const PtDevCamera cam = derive_camera(camera);
+    std::vector<int4> rects(n);
+    std::vector<uint64_t> states(n);
+    for(size_t i = 0; i < n; i++) {
+        const pt_stream &t = streams[i];
+        if(t.w < 0 || t.h < 0 || t.x < 0 || t.y < 0 || t.x + t.w > options->image_width || t.y + t.h > options->image_height) {
+            return fail(PT_ERR_INVALID, "stream rectangle outside the image");
+        }
+        rects[i] = make_int4(t.x, t.y, t.w, t.h);
+        states[i] = t.rng_state;
+    }
+    PT_HIP(hipSetDevice(s->device));
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    const size_t pixels = static_cast<size_t>(options->image_width) * static_cast<size_t>(options->image_height);
+    PT_HIP(s->image.ensure(pixels));
+    hipStream_t st = s->stream;
+    // pixels not covered by a stream keep the caller's values
+    PT_HIP(hipMemcpyAsync(s->image.ptr, out_image, pixels * sizeof(F4), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(s->rect.ptr, rects.data(), n * sizeof(int4), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(s->rng.ptr, states.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    pt_launch_init_streams(st, make_paths(s, n32));
+    rc = run_wavefront(s, cam, opt, n32, reinterpret_cast<float4 *>(s->image.ptr), stats);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    PT_HIP(hipMemcpyAsync(out_image, s->image.ptr, pixels * sizeof(F4), hipMemcpyDeviceToHost, st));
+    if(out_states != nullptr) {
+        PT_HIP(hipMemcpyAsync(out_states, s->rng.ptr, n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    }
+    PT_HIP(hipStreamSynchronize(st));
+    return PT_OK;
+}
+
+static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles, uint64_t base_seed,
+                             float4 *d_image, pt_stats *stats) {
+    PtDevOptions opt;
+    int rc = derive_options(options, &opt);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    const PtDevCamera cam = derive_camera(camera);
+    std::vector<int4> rects(n_tiles);
+    std::vector<uint32_t> offsets(n_tiles);
+    uint64_t total = 0;
+    for(size_t i = 0; i < n_tiles; i++) {
+        const pt_tile &t = tiles[i];
+        if(t.w <= 0 || t.h <= 0 || t.x < 0 || t.y < 0 || t.x + t.w > options->image_width || t.y + t.h > options->image_height) {
+            return fail(PT_ERR_INVALID, "tile outside the image or empty");
+        }
+        rects[i] = make_int4(t.x, t.y, t.w, t.h);
+        offsets[i] = static_cast<uint32_t>(total);
+        total += static_cast<uint64_t>(t.w) * static_cast<uint64_t>(t.h);
+    }
+    if(total > 0x3fffffffULL) {
+        return fail(PT_ERR_INVALID, "too many pixels in one call");
+    }
+    const uint32_t n32 = static_cast<uint32_t>(total);
+    rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    PT_HIP(s->tiles.ensure(n_tiles));
+    PT_HIP(s->tile_offset.ensure(n_tiles));
+    hipStream_t st = s->stream;
+    PT_HIP(hipMemcpyAsync(s->tiles.ptr, rects.data(), n_tiles * sizeof(int4), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(s->tile_offset.ptr, offsets.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    pt_launch_init_tiles(st, make_paths(s, n32), s->tiles.ptr, s->tile_offset.ptr, static_cast<uint32_t>(n_tiles), base_seed);
+    PT_HIP(hipStreamSynchronize(st)); // rects/offsets are stack-owned host vectors
+    return run_wavefront(s, cam, opt, n32, d_image, stats);
+}
+
+int pt_render_tiles(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles, uint64_t base_seed,
+                    float *out_image, pt_stats *stats) {
+    int rc = check_render_args(s, camera, options);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    if(stats != nullptr) {
+        std::memset(stats, 0, sizeof(*stats));
+    }
+    if(n_tiles == 0) {
+        return PT_OK;
+    }
+    if(tiles == nullptr || out_image == nullptr) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    PT_HIP(hipSetDevice(s->device));
+    const size_t pixels = static_cast<size_t>(options->image_width) * static_cast<size_t>(options->image_height);
+    PT_HIP(s->image.ensure(pixels));
+    PT_HIP(hipMemcpyAsync(s->image.ptr, out_image, pixels * sizeof(F4), hipMemcpyHostToDevice, s->stream));
+    rc = render_tiles_impl(s, camera, options, tiles, n_tiles, base_seed, reinterpret_cast<float4 *>(s->image.ptr), stats);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    PT_HIP(hipMemcpyAsync(out_image, s->image.ptr, pixels * sizeof(F4), hipMemcpyDeviceToHost, s->stream));
+    PT_HIP(hipStreamSynchronize(s->stream));
+    return PT_OK;
+}
+
+int pt_render_tiles_device(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles, uint64_t base_seed,
+                           float *d_out_image, void *stream, pt_stats *stats) {
+    int rc = check_render_args(s, camera, options);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    if(stats != nullptr) {
+        std::memset(stats, 0, sizeof(*stats));
+    }
+    if(n_tiles == 0) {
+        return PT_OK;
+    }
+    if(tiles == nullptr || d_out_image == nullptr) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    PT_HIP(hipSetDevice(s->device));
+    // order after the caller's stream, render on the library's stream, then make the caller's stream wait for it
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    hipEvent_t ev;
+    PT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    PT_HIP(hipEventRecord(ev, caller));
+    PT_HIP(hipStreamWaitEvent(s->stream, ev, 0));
+    rc = render_tiles_impl(s, camera, options, tiles, n_tiles, base_seed, reinterpret_cast<float4 *>(d_out_image), stats);
+    if(rc == PT_OK) {
+        PT_HIP(hipEventRecord(ev, s->stream));
+        PT_HIP(hipStreamWaitEvent(caller, ev, 0));
+    }
+    (void)hipEventDestroy(ev);
+    return rc;
+}
+
+} // extern "C"

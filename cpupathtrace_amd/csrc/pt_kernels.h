@@ -1,0 +1,70 @@
+// pt_kernels.h -- launch interface between the host side of libpathtrace_hip.so (pt_api.cpp) and its kernels.
+#ifndef PT_KERNELS_H
+#define PT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "pt_types.h"
+
+#define PT_SHARDS 8 /* ray-queue shards = XCDs; a workgroup appends to and first drains shard blockIdx.x % 8 */
+
+// Wavefront state of all streams in flight (structure of arrays, one element per stream slot).
+struct PtPaths {
+    uint32_t n;            // stream slots
+    int4 *rect;            // WorkItem rectangle x, y, w, h
+    uint64_t *rng;         // xorshift state of the stream's engine
+    int32_t *cursor;       // index of the current pixel inside the rectangle (row-major)
+    uint32_t *flags;       // PT_F_* bits
+    float4 *ray_o;         // current ray origin; w = contribution_unweighted (worker.cpp:38)
+    float4 *ray_d;         // current ray direction
+    float4 *spectrum;      // sample_spectrum (worker.cpp:41)
+    float4 *out;           // out_spectrum (worker.cpp:42)
+    double *divisor;       // sample_divisor (worker.cpp:39)
+    double *bounce_pd;     // sample_bounce_pd (worker.cpp:40)
+    int32_t *path_length;  // worker.cpp:43
+    float4 *nee;           // [PT_MAX_NEE][n] weighed_spectrum of the pending shadow rays (worker.cpp:97)
+    uint32_t *nee_mask;    // bit j: light sample j of the last vertex contributes if its shadow ray is unoccluded
+    PtEstimator *est;      // per-pixel estimator (worker.cpp:172-192)
+    PtCandidate *cand;     // [n][PT_MAX_CANDIDATES]
+    // results of the traversal kernel
+    uint2 *hit;            // [n] (bits t, ref) of the extension ray
+    uint32_t *vis;         // [n][PT_MAX_NEE] 1 = shadow ray unoccluded
+};
+
+#define PT_F_DONE 1u      /* the stream has rendered all its pixels */
+#define PT_F_IN_FLIGHT 2u /* a path is in flight (otherwise the next invocation starts a sample) */
+#define PT_F_HAS_EXT 4u   /* an extension (camera/bounce) ray was traced for it */
+#define PT_F_COLLECTED 8u /* sample_collected (worker.cpp:37) */
+#define PT_F_PIXEL 16u    /* the estimator of the current pixel is initialised */
+
+// Ray queue: PT_SHARDS append-only segments of `shard_capacity` rays each.
+struct PtQueue {
+    float4 *ray_o;   // origin xyz, w = shadow threshold |to_light| - epsilon (worker.cpp:86) or unused
+    float4 *ray_d;   // direction xyz, w = bits destination: bit 31 = shadow ray, low bits = slot (ext) or slot * PT_MAX_NEE + j
+    uint32_t *count; // [PT_SHARDS] rays appended
+    uint32_t *head;  // [PT_SHARDS] rays dequeued
+    uint32_t shard_capacity;
+};
+
+#define PT_DEST_SHADOW 0x80000000u
+#define PT_DEST_NULL 0xffffffffu /* hole in the queue: reserved but not used */
+
+struct PtTraceConfig {
+    int grid;
+    int stack_lds;        // stack entries per lane kept in LDS
+    uint32_t spill_depth; // further entries per lane in HBM
+    uint2 *spill;
+    size_t lds_bytes;
+};
+
+void pt_launch_init_tiles(hipStream_t stream, PtPaths paths, const int4 *tiles, const uint32_t *tile_offset, uint32_t n_tiles, uint64_t base_seed);
+void pt_launch_init_streams(hipStream_t stream, PtPaths paths);
+void pt_launch_shade(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtPaths paths, PtQueue queue,
+                     float4 *image, PtDevCounters *counters);
+void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters);
+void pt_launch_batch_rays(hipStream_t stream, const float *rays6, uint32_t n, PtQueue queue);
+int pt_trace_blocks_per_cu(int stack_lds, size_t lds_bytes);
+
+uint64_t pt_host_pixel_seed(uint64_t base_seed, int32_t x, int32_t y);
+
+#endif

@@ -1,0 +1,664 @@
+// pt_shade.hip -- the per-path state machine: camera ray generation, vertex shading with next-event estimation, Russian
+// roulette, BSDF sampling (impl::getSample, src/worker.cpp:26-146) and the per-pixel adaptive estimator
+// (processItem, src/worker.cpp:149-326), one stream slot per lane.
+//
+// One wavefront iteration = one launch of this kernel + one launch of the traversal kernel (pt_trace.hip):
+//   shade(i):  every stream with a path in flight first adds the shadow-ray results of its previous vertex to out_spectrum in
+//              the reference's order (worker.cpp:76-103), then looks at the extension ray's hit: miss -> the sample is
+//              finished; hit -> shade that vertex: emission (worker.cpp:62-64), Russian-roulette draw (:67-70), light sampling
+//              (Scene::sampleLights, scene.cpp:222-289) with one shadow ray per light sample, BSDF sample (:117-131).
+//              A finished sample goes through the estimator and the stream immediately starts its next sample (or pixel).
+//   trace(i):  all rays appended by shade(i).
+// The random draws of one stream are consumed strictly in the reference's order because a stream has at most one path in
+// flight and every draw of a vertex (roulette, lights, BSDF) is made by the single invocation that shades the vertex.
+//
+// Rays are appended to the queue shard of this workgroup (blockIdx.x % 8): each lane reserves its worst case
+// (1 extension ray + L + k shadow rays) and the wave makes ONE atomic for all lanes, lane offsets coming from
+// ballot/popcount prefix sums; light samples that turn out not to need a ray leave a PT_DEST_NULL hole.
+#include "pt_device.h"
+#include "pt_kernels.h"
+
+using namespace ptd;
+
+namespace {
+
+PT_D C4 ld4(const float *p) {
+    return c4(p[0], p[1], p[2], p[3]);
+}
+PT_D void st4(float *p, C4 c) {
+    p[0] = c.r;
+    p[1] = c.g;
+    p[2] = c.b;
+    p[3] = c.a;
+}
+PT_D float4 f4(C4 c) {
+    return make_float4(c.r, c.g, c.b, c.a);
+}
+
+// worker.cpp:12-14
+PT_D float get_contribution(C4 c) {
+    return (c.r + c.g + c.b) / 3.0f;
+}
+
+PT_D uint64_t pixel_seed(uint64_t base, int32_t x, int32_t y) {
+    uint64_t z = base + 0x9E3779B97F4A7C15ULL * (1ULL + (((uint64_t)(uint32_t)y) << 32) + (uint64_t)(uint32_t)x);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// ---- per-pixel estimator: the body of processItem's sample loop after getSample returned (worker.cpp:196-260) -------------
+// returns true when the loop breaks with accepted_candidate
+PT_D bool estimator_add(PtEstimator &e, PtCandidate *cand, const PtDevOptions &opt, C4 color_contribution) {
+    e.contribution_count++;
+    e.stats_sample_index++;
+    C4 agg = ld4(e.sample_aggregate) + color_contribution;
+
+    if(e.stats_sample_index == opt.stats_sample_count) {
+        agg = agg / (float)opt.stats_sample_count;
+
+        C4 mean = ld4(e.contribution_mean);
+        C4 delta = agg - mean;
+        mean = mean + delta / (float)(e.contribution_count / opt.stats_sample_count);
+        C4 delta2 = agg - mean;
+        st4(e.contribution_mean, mean);
+        st4(e.contribution_m2, ld4(e.contribution_m2) + delta * delta2);
+
+        if(e.candidate_count == opt.candidate_batch_count) {
+            if(e.n_candidates < PT_MAX_CANDIDATES) {
+                PtCandidate &c = cand[e.n_candidates];
+                for(int k = 0; k < 4; k++) {
+                    c.mean[k] = e.candidate_mean[k];
+                    c.m2[k] = e.candidate_m2[k];
+                }
+                c.count = e.candidate_count;
+            }
+            e.n_candidates++;
+            st4(e.candidate_mean, c4(0, 0, 0, 0));
+            st4(e.candidate_m2, c4(0, 0, 0, 0));
+            e.candidate_count = 0;
+        }
+
+        e.candidate_count++;
+        C4 cmean = ld4(e.candidate_mean);
+        C4 cdelta = agg - cmean;
+        cmean = cmean + cdelta / (float)e.candidate_count;
+        C4 cdelta2 = agg - cmean;
+        st4(e.candidate_mean, cmean);
+        st4(e.candidate_m2, ld4(e.candidate_m2) + cdelta * cdelta2);
+
+        e.stats_sample_index = 0;
+        agg = c4(0, 0, 0, 0);
+    }
+    st4(e.sample_aggregate, agg);
+
+    st4(e.pixel_value, ld4(e.pixel_value) + color_contribution);
+    e.collected_sample_count++;
+
+    const int min_needed = opt.min_sample_count > 2 ? opt.min_sample_count : 2;
+    if(e.stats_sample_index == 0 && e.collected_sample_count >= min_needed) {
+        bool passed_check = false;
+        const int batches = e.contribution_count / opt.stats_sample_count;
+        if(batches >= 2) {
+            C4 m2w = ld4(e.contribution_m2) / (float)(batches - 1);
+            float stddev = __builtin_sqrtf(m2w.r + m2w.g + m2w.b);
+            // worker.cpp:245: the 1E-5 literal promotes the ratio to double
+            if(stddev < 1E-4f || (double)stddev / ((double)(9.0f * get_contribution(ld4(e.contribution_mean))) + 1E-5) < (double)0.2f) {
+                passed_check = true;
+                e.remaining_checks--;
+                if(e.remaining_checks <= 0) {
+                    return true;
+                }
+            }
+        }
+        if(!passed_check) {
+            e.remaining_checks = opt.check_sample_count;
+        }
+    }
+    return false;
+}
+
+// after the sample loop: worker.cpp:263-319
+PT_D C4 estimator_finish(PtEstimator &e, PtCandidate *cand, const PtDevOptions &opt, bool accepted) {
+    C4 pixel_value = ld4(e.pixel_value);
+    if(e.collected_sample_count > 0) {
+        pixel_value = pixel_value * (1.0f / (float)e.collected_sample_count);
+    }
+    if(accepted) {
+        return pixel_value;
+    }
+    int n = e.n_candidates < PT_MAX_CANDIDATES ? e.n_candidates : PT_MAX_CANDIDATES;
+    // the open candidate is appended (worker.cpp:267-271)
+    const bool has_open = e.candidate_count > 0;
+    const int min_count = (opt.candidate_batch_count * 3) / 4 > 2 ? (opt.candidate_batch_count * 3) / 4 : 2;
+
+    // qualifying candidates, insertion-sorted by stddev the way std::sort orders <= 16 elements (libstdc++ __insertion_sort)
+    float sd[PT_MAX_CANDIDATES + 1];
+    int id[PT_MAX_CANDIDATES + 1];
+    int m = 0;
+    for(int i = 0; i < n + (has_open ? 1 : 0); i++) {
+        int count;
+        C4 m2;
+        if(i < n) {
+            count = cand[i].count;
+            m2 = ld4(cand[i].m2);
+        }
+        else {
+            count = e.candidate_count;
+            m2 = ld4(e.candidate_m2);
+        }
+        if(count < min_count) {
+            continue;
+        }
+        C4 m2w = m2 / (float)count;
+        float stddev = __builtin_sqrtf(m2w.r + m2w.g + m2w.b);
+        int j = m;
+        if(m > 0 && stddev < sd[0]) {
+            for(; j > 0; j--) {
+                sd[j] = sd[j - 1];
+                id[j] = id[j - 1];
+            }
+        }
+        else {
+            while(j > 0 && stddev < sd[j - 1]) {
+                sd[j] = sd[j - 1];
+                id[j] = id[j - 1];
+                j--;
+            }
+        }
+        sd[j] = stddev;
+        id[j] = i;
+        m++;
+    }
+    if(m == 0) {
+        return pixel_value;
+    }
+    auto mean_of = [&](int i) { return i < n ? ld4(cand[i].mean) : ld4(e.candidate_mean); };
+    pixel_value = mean_of(id[0]);
+    float stddev = sd[0];
+    for(int i = 1; i < m; i++) {
+        float stddev_other = sd[i];
+        if(stddev_other < fmax_std(stddev + 0.005f, stddev * 1.01f)) {
+            pixel_value = pixel_value + (mean_of(id[i]) - pixel_value) / (float)(i + 1);
+            stddev = stddev_other;
+        }
+        else {
+            break;
+        }
+    }
+    return pixel_value;
+}
+
+PT_D void estimator_reset(PtEstimator &e, const PtDevOptions &opt) {
+    for(int k = 0; k < 4; k++) {
+        e.pixel_value[k] = 0.0f;
+        e.contribution_mean[k] = 0.0f;
+        e.contribution_m2[k] = 0.0f;
+        e.sample_aggregate[k] = 0.0f;
+        e.candidate_mean[k] = 0.0f;
+        e.candidate_m2[k] = 0.0f;
+    }
+    e.collected_sample_count = 0;
+    e.contribution_count = 0;
+    e.stats_sample_index = 0;
+    e.candidate_count = 0;
+    e.remaining_checks = opt.check_sample_count;
+    e.n_candidates = 0;
+    e.pixel_sample = 0;
+    e.pad = 0;
+}
+
+// ---- Scene::sampleLights, one light sample (scene.cpp:238-286) ----------------------------------------------------------
+// Draws 3 numbers; returns false when the reference `continue`s.
+PT_D bool sample_emissive(const PtDevScene &sc, V3 pos, uint64_t &rng, V3 &light_pos, C4 &spectrum, float &pd) {
+    const float r = rng_uniform01(rng);
+    // std::lower_bound over the CDF
+    int lo = 0, n = (int)sc.n_emis;
+    while(n > 0) {
+        const int half = n >> 1;
+        if(sc.emis_cdf[lo + half] < r) {
+            lo = lo + half + 1;
+            n = n - half - 1;
+        }
+        else {
+            n = half;
+        }
+    }
+    const int object_index = lo;
+    float selection_p = sc.emis_cdf[object_index];
+    if(object_index > 0) {
+        selection_p -= sc.emis_cdf[object_index - 1];
+    }
+    selection_p *= (float)sc.n_object_samples;
+
+    const float4 *rec = sc.emis + 4 * (size_t)object_index;
+    const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
+    const uint32_t ref = __float_as_uint(e2.y);
+    V3 surface_pos, surface_n;
+    float surface_p;
+    bool surface_cull;
+    if(ref & PT_REF_SPHERE) {
+        // Sphere::sampleSurface, object.cpp:101-116
+        const V3 origin = v3(e0.x, e0.y, e0.z);
+        const float radius = e0.w;
+        const float radius2 = radius * radius;
+        const float theta = 2.0f * PT_PI_F * rng_uniform01(rng);
+        const float phi = ptm::acosf_glibc(1.0f - 2.0f * rng_uniform01(rng));
+        const float x = ptm::sinf_glibc(phi) * ptm::cosf_glibc(theta);
+        const float y = ptm::sinf_glibc(phi) * ptm::sinf_glibc(theta);
+        const float z = ptm::cosf_glibc(phi);
+        surface_pos = origin + v3(x, y, z) * radius;
+        surface_p = 1.0f / (4.0f * PT_PI_F * radius2);
+        surface_cull = false;
+        surface_n = normalize(surface_pos - origin);
+    }
+    else {
+        // Triangle::sampleSurface, object.cpp:192-207
+        const V3 a = v3(e0.x, e0.y, e0.z), b = v3(e0.w, e1.x, e1.y), c = v3(e1.z, e1.w, e2.x);
+        const float r1 = rng_uniform01(rng);
+        const float r2 = rng_uniform01(rng);
+        const float rr1 = __builtin_sqrtf(r1);
+        surface_pos = (a * (1.0f - rr1) + b * (rr1 * (1.0f - r2))) + c * (rr1 * r2);
+        const float area = len(cross(b - a, c - a)) / 2.0f;
+        surface_p = 1.0f / area;
+        surface_cull = __float_as_uint(e2.z) != 0;
+        uint32_t mat_unused;
+        surface_n = object_normal(sc, ref, surface_pos, mat_unused);
+    }
+
+    const V3 to_light = surface_pos - pos;
+    const V3 dir = normalize(to_light);
+    const float abs_dot = __builtin_fabsf(dot(neg(dir), surface_n));
+    if(!(abs_dot > 0.0f)) {
+        return false;
+    }
+    if(!(len2(to_light) > 0.0f)) {
+        return false;
+    }
+    if(surface_cull) {
+        if(!(dot(dir, surface_n) < 0.0f)) {
+            return false;
+        }
+    }
+    const float conversion_factor = len2(to_light) / abs_dot;
+    light_pos = surface_pos;
+    spectrum = c4(e3);
+    pd = selection_p * surface_p * conversion_factor;
+    return true;
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamera cam, PtDevOptions opt, PtPaths P, PtQueue q, float4 *__restrict__ image,
+                                                       PtDevCounters *counters) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t shard = blockIdx.x % PT_SHARDS;
+    const uint32_t n_light_samples = sc.n_lights + sc.n_object_samples;
+
+    uint32_t flags = PT_F_DONE;
+    if(p < P.n) {
+        flags = P.flags[p];
+    }
+    const bool alive = !(flags & PT_F_DONE);
+
+    // ---- phase A: consume the results of the previous iteration ------------------------------------------------------
+    uint64_t rng = 0;
+    C4 out = c4(0, 0, 0, 0), spectrum = c4(1, 1, 1, 1);
+    V3 ro = v3(0, 0, 0), rd = v3(0, 0, 1);
+    float contribution_unweighted = 1.0f;
+    double divisor = 1.0, bounce_pd = 1.0;
+    int path_length = 0;
+    bool shade_vertex = false; // the extension ray hit something
+    bool start_sample = false; // generate a camera ray
+    float hit_t = -1.0f;
+    uint32_t hit_ref = PT_REF_NONE;
+    unsigned long long n_samples = 0, n_vertices = 0;
+
+    if(alive) {
+        rng = P.rng[p];
+        if(flags & PT_F_IN_FLIGHT) {
+            out = c4(P.out[p]);
+            // shadow rays of the previous vertex, in light order (worker.cpp:76-103)
+            uint32_t mask = P.nee_mask[p];
+            for(uint32_t j = 0; mask != 0; j++, mask >>= 1) {
+                if((mask & 1u) && P.vis[(size_t)p * PT_MAX_NEE + j] != 0u) {
+                    out = out + c4(P.nee[(size_t)j * P.n + p]);
+                }
+            }
+            bool finished = true;
+            if(flags & PT_F_HAS_EXT) {
+                const uint2 h = P.hit[p];
+                hit_t = __uint_as_float(h.x);
+                hit_ref = h.y;
+                if(!(hit_t < 0.0f)) {
+                    finished = false;
+                    shade_vertex = true;
+                }
+            }
+            if(finished) {
+                // getSample returns (worker.cpp:141-145); run the estimator
+                PtEstimator e = P.est[p];
+                PtCandidate *cand = P.cand + (size_t)p * PT_MAX_CANDIDATES;
+                bool accepted = false;
+                if(flags & PT_F_COLLECTED) {
+                    out.a = 1.0f;
+                    accepted = estimator_add(e, cand, opt, out);
+                }
+                e.pixel_sample++;
+                n_samples++;
+                if(accepted || e.pixel_sample >= opt.max_sample_count) {
+                    // pixel finished (worker.cpp:263-319)
+                    const C4 value = estimator_finish(e, cand, opt, accepted);
+                    const int4 rc = P.rect[p];
+                    const int32_t cur = P.cursor[p];
+                    const int32_t px = rc.x + cur % rc.z, py = rc.y + cur / rc.z;
+                    image[(size_t)py * opt.image_width + px] = f4(value);
+                    P.cursor[p] = cur + 1;
+                    flags &= ~PT_F_PIXEL;
+                }
+                P.est[p] = e;
+                flags &= ~(PT_F_IN_FLIGHT | PT_F_HAS_EXT | PT_F_COLLECTED);
+                start_sample = true;
+            }
+            else {
+                const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
+                ro = v3(o4.x, o4.y, o4.z);
+                rd = v3(d4.x, d4.y, d4.z);
+                contribution_unweighted = o4.w;
+                spectrum = c4(P.spectrum[p]);
+                divisor = P.divisor[p];
+                bounce_pd = P.bounce_pd[p];
+                path_length = P.path_length[p];
+            }
+        }
+        else {
+            start_sample = true;
+        }
+    }
+
+    // ---- start the next sample / pixel ------------------------------------------------------------------------------------
+    bool emit_ext = false;
+    Ray ext;
+    ext.o = v3(0, 0, 0);
+    ext.d = v3(0, 0, 1);
+    if(start_sample) {
+        const int4 rc = P.rect[p];
+        int32_t cur = P.cursor[p];
+        bool have_pixel = false;
+        while(cur < rc.z * rc.w) {
+            if(!(flags & PT_F_PIXEL)) {
+                PtEstimator e;
+                estimator_reset(e, opt);
+                P.est[p] = e;
+                flags |= PT_F_PIXEL;
+                if(opt.max_sample_count <= 0) {
+                    // no sample at all: the pixel stays (0, 0, 0, 0) (worker.cpp:193,263-265)
+                    const int32_t px = rc.x + cur % rc.z, py = rc.y + cur / rc.z;
+                    image[(size_t)py * opt.image_width + px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    cur++;
+                    flags &= ~PT_F_PIXEL;
+                    continue;
+                }
+            }
+            have_pixel = true;
+            break;
+        }
+        P.cursor[p] = cur;
+        if(!have_pixel) {
+            flags = PT_F_DONE;
+            atomicAdd(&counters->streams_done, 1ULL);
+        }
+        else {
+            // worker.cpp:168-170
+            const int32_t px = rc.x + cur % rc.z, py = rc.y + cur / rc.z;
+            const float one_half = 1.0f / 2.0f;
+            const float x_camera = 2 * (((float)px + one_half) / (float)opt.image_width - one_half);
+            float y_camera = 2 * (((float)py + one_half) / (float)opt.image_height - one_half);
+            y_camera = -y_camera;
+            ext = camera_shoot(cam, x_camera, y_camera, opt.pixel_width, opt.pixel_height, rng);
+            emit_ext = true;
+            out = c4(0, 0, 0, 0);
+            spectrum = c4(1, 1, 1, 1);
+            contribution_unweighted = 1.0f;
+            divisor = 1.0;
+            bounce_pd = 1.0;
+            path_length = 0;
+            flags |= PT_F_IN_FLIGHT | PT_F_HAS_EXT;
+        }
+    }
+
+    // ---- vertex, part 1: everything up to the Russian-roulette draw (worker.cpp:50-70) ---------------------------------------
+    V3 pos = v3(0, 0, 0), n = v3(0, 1, 0);
+    Material mat;
+    mat.bsdf = 0;
+    bool do_bounce = false;
+    float bounce_probability = 1.0f;
+    bool want_nee = false;
+    if(shade_vertex) {
+        path_length++;
+        flags |= PT_F_COLLECTED;
+        n_vertices++;
+        pos = ro + rd * hit_t;
+        uint32_t material_index;
+        n = object_normal(sc, hit_ref, pos, material_index);
+        mat = material_load(sc.materials, material_index);
+
+        out = out + (spectrum * mat.emission) / (float)(divisor * bounce_pd);
+
+        bounce_probability = path_length <= 4 ? 1.0f : 0.1f + 0.1f * fmin_std(contribution_unweighted * get_contribution(spectrum), 1.0f);
+        do_bounce = rng_uniform01(rng) < bounce_probability;
+        // BSDF::getSpectrum(..., synthetic = true) returns p = 0 for glass and mirror: their light samples never
+        // contribute (worker.cpp:92), so no shadow ray is needed -- the light-sampling draws are still consumed below.
+        want_nee = mat.bsdf == 0 && n_light_samples > 0;
+        emit_ext = do_bounce; // may still be cancelled by the 1E-20 guards (worker.cpp:112,134)
+    }
+
+    // ---- reserve queue space: one atomic per wave -----------------------------------------------------------------------------
+    const unsigned long long ext_mask = __ballot(emit_ext);
+    const unsigned long long nee_mask_w = __ballot(want_nee);
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    const uint32_t wave_total = (uint32_t)__popcll(ext_mask) + n_light_samples * (uint32_t)__popcll(nee_mask_w);
+    uint32_t wave_base = 0;
+    if(wave_total > 0) {
+        if(lane == 0) {
+            wave_base = atomicAdd(&q.count[shard], wave_total);
+        }
+        wave_base = __builtin_amdgcn_readfirstlane(wave_base);
+    }
+    const size_t slot0 = (size_t)shard * q.shard_capacity + wave_base + (uint32_t)__popcll(ext_mask & lt) + n_light_samples * (uint32_t)__popcll(nee_mask_w & lt);
+    // this lane's extension ray goes to slot0, its shadow rays to slot0 + (emit_ext ? 1 : 0) + j
+
+    // ---- vertex, part 2: light sampling, shadow rays, bounce (worker.cpp:73-138) -------------------------------------------------
+    uint32_t nee_out_mask = 0;
+    if(shade_vertex) {
+        const float epsilon = opt.epsilon;
+        const size_t nee_slot = slot0 + (emit_ext ? 1 : 0);
+        for(uint32_t j = 0; j < n_light_samples; j++) {
+            V3 light_pos;
+            C4 light_spectrum;
+            float lpd;
+            bool valid;
+            if(j < sc.n_lights) {
+                // PointLightSource: its position, its spectrum, pd = 1 (light.cpp:35-41)
+                const float4 lp = sc.lights[2 * j];
+                light_pos = v3(lp.x, lp.y, lp.z);
+                light_spectrum = c4(sc.lights[2 * j + 1]);
+                lpd = 1.0f;
+                valid = true;
+            }
+            else {
+                valid = sample_emissive(sc, pos, rng, light_pos, light_spectrum, lpd);
+            }
+            bool need_ray = false;
+            if(valid && want_nee) {
+                const V3 to_light = light_pos - pos;
+                const V3 light_dir = normalize(to_light);
+                float shading_factor, shadow_ray_pd;
+                const C4 base_spectrum = bsdf_spectrum(mat, rd, light_dir, n, light_spectrum, true, shading_factor, shadow_ray_pd);
+                if(shadow_ray_pd > 0.0f) {
+                    const C4 combined = (base_spectrum * shading_factor) * spectrum;
+                    const C4 weighed = combined / (float)(divisor * bounce_pd * lpd * shadow_ray_pd);
+                    // adding +-0 never changes out_spectrum (which is never -0), so such a sample needs no ray
+                    if(!(weighed.r == 0.0f && weighed.g == 0.0f && weighed.b == 0.0f)) {
+                        P.nee[(size_t)j * P.n + p] = f4(weighed);
+                        nee_out_mask |= 1u << j;
+                        const float threshold = len(to_light) - epsilon;
+                        if(threshold <= 0.0f) {
+                            // light_t < 0 || light_t >= threshold holds for every light_t
+                            P.vis[(size_t)p * PT_MAX_NEE + j] = 1u;
+                        }
+                        else {
+                            need_ray = true;
+                            const V3 so = pos + light_dir * epsilon;
+                            q.ray_o[nee_slot + j] = make_float4(so.x, so.y, so.z, threshold);
+                            q.ray_d[nee_slot + j] =
+                              make_float4(light_dir.x, light_dir.y, light_dir.z, __uint_as_float(PT_DEST_SHADOW | (p * PT_MAX_NEE + j)));
+                        }
+                    }
+                }
+            }
+            if(want_nee && !need_ray) {
+                q.ray_d[nee_slot + j] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PT_DEST_NULL));
+            }
+        }
+
+        bool cancel_ext = false;
+        if(!do_bounce) {
+            // worker.cpp:106-109: the path ends here
+        }
+        else {
+            bounce_pd *= bounce_probability;
+            if(bounce_pd <= 1E-20) {
+                cancel_ext = true;
+            }
+            else {
+                float ray_factor, ray_pd;
+                const Ray next_ray = bsdf_propagate(mat, rd, pos, n, epsilon, rng, ray_factor, ray_pd);
+                divisor *= ray_pd;
+                divisor /= ray_factor;
+                contribution_unweighted *= ray_factor;
+                float shading_factor, shading_pd;
+                const C4 shaded = bsdf_spectrum(mat, rd, next_ray.d, n, spectrum, false, shading_factor, shading_pd);
+                divisor *= shading_pd;
+                divisor /= shading_factor;
+                contribution_unweighted *= shading_factor;
+                spectrum = shaded;
+                if(divisor <= 1E-20) {
+                    cancel_ext = true;
+                }
+                else {
+                    ext = next_ray;
+                }
+            }
+        }
+        if(emit_ext && cancel_ext) {
+            q.ray_d[slot0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PT_DEST_NULL));
+            emit_ext = false;
+        }
+        if(emit_ext) {
+            flags |= PT_F_HAS_EXT;
+        }
+        else {
+            flags &= ~PT_F_HAS_EXT;
+        }
+    }
+
+    // ---- write the extension ray and the path state ------------------------------------------------------------------------------
+    if(emit_ext) {
+        q.ray_o[slot0] = make_float4(ext.o.x, ext.o.y, ext.o.z, 0.0f);
+        q.ray_d[slot0] = make_float4(ext.d.x, ext.d.y, ext.d.z, __uint_as_float(p));
+    }
+    if(alive) {
+        P.flags[p] = flags;
+        P.rng[p] = rng;
+        if(!(flags & PT_F_DONE)) {
+            P.ray_o[p] = make_float4(ext.o.x, ext.o.y, ext.o.z, contribution_unweighted);
+            P.ray_d[p] = make_float4(ext.d.x, ext.d.y, ext.d.z, 0.0f);
+            P.spectrum[p] = f4(spectrum);
+            P.out[p] = f4(out);
+            P.divisor[p] = divisor;
+            P.bounce_pd[p] = bounce_pd;
+            P.path_length[p] = path_length;
+            P.nee_mask[p] = nee_out_mask;
+        }
+    }
+
+    // counters: one atomic per wave
+    for(int off = 32; off > 0; off >>= 1) {
+        n_samples += __shfl_down(n_samples, off);
+        n_vertices += __shfl_down(n_vertices, off);
+    }
+    if(lane == 0 && (n_samples | n_vertices)) {
+        atomicAdd(&counters->samples, n_samples);
+        atomicAdd(&counters->vertices, n_vertices);
+    }
+}
+
+__global__ void pt_init_tiles_kernel(PtPaths P, const int4 *__restrict__ tiles, const uint32_t *__restrict__ tile_offset, uint32_t n_tiles, uint64_t base_seed) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= P.n) {
+        return;
+    }
+    // binary search for the tile holding slot p
+    uint32_t lo = 0, hi = n_tiles;
+    while(hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if(tile_offset[mid] <= p) {
+            lo = mid;
+        }
+        else {
+            hi = mid;
+        }
+    }
+    const int4 t = tiles[lo];
+    const uint32_t k = p - tile_offset[lo];
+    const int32_t x = t.x + (int32_t)(k % (uint32_t)t.z), y = t.y + (int32_t)(k / (uint32_t)t.z);
+    P.rect[p] = make_int4(x, y, 1, 1);
+    const uint64_t seed = pixel_seed(base_seed, x, y);
+    P.rng[p] = seed ^ (~seed << 32); // RandomEngine(seed), base.h:26
+    P.cursor[p] = 0;
+    P.flags[p] = 0;
+    P.nee_mask[p] = 0;
+}
+
+__global__ void pt_init_streams_kernel(PtPaths P) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= P.n) {
+        return;
+    }
+    P.cursor[p] = 0;
+    P.flags[p] = 0;
+    P.nee_mask[p] = 0;
+}
+
+} // namespace
+
+uint64_t pt_host_pixel_seed(uint64_t base, int32_t x, int32_t y) {
+    uint64_t z = base + 0x9E3779B97F4A7C15ULL * (1ULL + (((uint64_t)(uint32_t)y) << 32) + (uint64_t)(uint32_t)x);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+void pt_launch_init_tiles(hipStream_t stream, PtPaths paths, const int4 *tiles, const uint32_t *tile_offset, uint32_t n_tiles, uint64_t base_seed) {
+    if(paths.n == 0) {
+        return;
+    }
+    hipLaunchKernelGGL(pt_init_tiles_kernel, dim3((paths.n + 255) / 256), dim3(256), 0, stream, paths, tiles, tile_offset, n_tiles, base_seed);
+}
+
+void pt_launch_init_streams(hipStream_t stream, PtPaths paths) {
+    if(paths.n == 0) {
+        return;
+    }
+    hipLaunchKernelGGL(pt_init_streams_kernel, dim3((paths.n + 255) / 256), dim3(256), 0, stream, paths);
+}
+
+void pt_launch_shade(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtPaths paths, PtQueue queue,
+                     float4 *image, PtDevCounters *counters) {
+    if(paths.n == 0) {
+        return;
+    }
+    hipLaunchKernelGGL(pt_shade_kernel, dim3((paths.n + 255) / 256), dim3(256), 0, stream, scene, camera, options, paths, queue, image, counters);
+}

@@ -1,0 +1,351 @@
+// pt_trace.hip -- closest-hit / shadow traversal of the reference's BVH: persistent wavefronts over a sharded ray queue.
+//
+// What it computes: Scene::getIntersection (src/scene/scene.cpp:210-220) = root slab test + the ordered recursive
+// impl::getChildIntersection (scene.cpp:104-150), restated as an iterative depth-first walk that visits exactly the leaves
+// the recursion visits, in the same order:
+//   * at an inner node both child boxes are tested (bounding_box.cpp:38-73); the nearer child is entered first, on equal entry
+//     distances the RIGHT child is the nearer one (scene.cpp:120-121);
+//   * a child is entered only if 0 <= entry < t_max (scene.cpp:124,137), where t_max is the smallest hit distance found so
+//     far -- in the recursion t_max is threaded by value, but at every decision point it equals that global minimum, and
+//     the early return of scene.cpp:129-132 is the same test (close hit < far entry  <=>  far entry >= t_max);
+//   * the far child is parked on a per-lane stack TOGETHER with its entry distance and re-tested against the then-current
+//     t_max when it is popped;
+//   * a leaf reports Object::getIntersection unconditionally (scene.cpp:105-109); among non-negative hits the smallest wins
+//     and a later-visited leaf wins ties (scene.cpp:141-146).
+// Shadow rays (worker.cpp:84-86) only need "is there a visited leaf with 0 <= t < |to_light| - epsilon"; the walk stops at
+// the first such leaf, which cannot change the answer.
+//
+// How it maps to gfx950:
+//   * one ray per lane, 256-thread workgroups, persistent: a wavefront refills its idle lanes from the queue whenever at least
+//     PT_REFILL_IDLE lanes are idle (ballot + popcount + one atomic per refill; lane i takes the i-th fetched ray by
+//     prefix-popcount of the idle mask), so lanes that drew short traversals do not wait for the longest one;
+//   * the queue has one shard per XCD: a workgroup drains shard blockIdx.x % 8 first (rays appended by shading workgroups
+//     of the same residue, i.e. neighbouring pixels share an L2), then steals from the others;
+//   * inner nodes are 64-byte records holding BOTH child boxes, so a traversal step is one 64-byte fetch (4 x dwordx4) per
+//     lane; the breadth-first top of the tree and, for small scenes, the triangle records are staged in LDS once per
+//     workgroup; everything else is a random HBM/L2 fetch -- the kernel is bound by memory latency/bandwidth, there is no
+//     matrix work in it (no MFMA);
+//   * the traversal stack lives in LDS ([level][lane] layout: conflict-free ds_read_b64/ds_write_b64), with the rare
+//     overflow beyond PT_STACK_LDS levels going to a per-lane HBM spill area.
+#include "pt_device.h"
+#include "pt_kernels.h"
+
+using namespace ptd;
+
+#define PT_REFILL_IDLE 20 /* refill once this many of the 64 lanes are idle */
+
+namespace {
+
+struct TraceLds {
+    uint2 *stack;        // [stack_lds][256]
+    const float4 *pairs; // [n_lds_pairs * 4]
+    const float4 *tris;  // [n_lds_tris * 3]
+};
+
+template<int STACK_LDS, bool COUNT>
+__global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, uint2 *__restrict__ hit, uint32_t *__restrict__ vis,
+                                                       uint2 *__restrict__ spill, uint32_t spill_depth, PtDevCounters *counters) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    uint2 *lds_stack = reinterpret_cast<uint2 *>(lds_raw);
+    float4 *lds_pairs = reinterpret_cast<float4 *>(lds_raw + (size_t)STACK_LDS * 256 * sizeof(uint2));
+    float4 *lds_tris = lds_pairs + 4 * (size_t)sc.n_lds_pairs;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    // stage the top of the tree (and the triangles of small scenes) in LDS
+    for(uint32_t i = tid; i < 4 * sc.n_lds_pairs; i += 256) {
+        lds_pairs[i] = sc.pairs[i];
+    }
+    for(uint32_t i = tid; i < 3 * sc.n_lds_tris; i += 256) {
+        lds_tris[i] = sc.tris[i];
+    }
+    __syncthreads();
+
+    uint2 *my_spill = spill + ((size_t)blockIdx.x * 256 + tid) * spill_depth;
+
+    // wave-uniform queue cursor
+    uint32_t shard = blockIdx.x % PT_SHARDS;
+    uint32_t shards_tried = 0;
+    bool exhausted = false;
+
+    // per-lane traversal state
+    bool active = false;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 0), inv = v3(0, 0, 0);
+    float thr = 0.0f;     // shadow threshold
+    uint32_t dest = 0;    // destination word of the ray
+    float best_t = 0.0f;
+    uint32_t best_ref = PT_REF_NONE;
+    float t_max = FLT_MAX;
+    uint32_t cur = PT_REF_NONE;
+    int sp = 0;
+    uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0;
+
+    for(;;) {
+        // ---- refill idle lanes -------------------------------------------------------------------------------------
+        const unsigned long long idle_mask = __ballot(!active);
+        const int n_idle = __popcll(idle_mask);
+        if(!exhausted && n_idle >= PT_REFILL_IDLE) {
+            uint32_t first = 0, avail = 0;
+            while(!exhausted) {
+                const uint32_t count = q.count[shard];
+                uint32_t base = 0;
+                if(lane == 0) {
+                    base = atomicAdd(&q.head[shard], (uint32_t)n_idle);
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+                if(base < count) {
+                    first = shard * q.shard_capacity + base;
+                    avail = count - base;
+                    break;
+                }
+                shard = (shard + 1) % PT_SHARDS;
+                if(++shards_tried >= PT_SHARDS) {
+                    exhausted = true;
+                }
+            }
+            if(!exhausted && !active) {
+                const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
+                if(rank < avail) {
+                    const float4 ro = q.ray_o[first + rank];
+                    const float4 rd = q.ray_d[first + rank];
+                    dest = __float_as_uint(rd.w);
+                    if(dest != PT_DEST_NULL) {
+                        o = v3(ro.x, ro.y, ro.z);
+                        d = v3(rd.x, rd.y, rd.z);
+                        thr = ro.w;
+                        inv = slab_inverse(d);
+                        best_ref = PT_REF_NONE;
+                        best_t = -1.0f;
+                        t_max = FLT_MAX;
+                        sp = 0;
+                        active = true;
+                        if(COUNT) {
+                            n_rays++;
+                            n_shadow += (dest & PT_DEST_SHADOW) ? 1 : 0;
+                        }
+                        // Scene::getIntersection: root box first (scene.cpp:211-219)
+                        cur = PT_REF_NONE;
+                        if(sc.root_ref != PT_REF_NONE) {
+                            const float t_root = slab_test(ld3(sc.root_lo), ld3(sc.root_hi), o, inv);
+                            if(t_root >= 0.0f) {
+                                cur = sc.root_ref;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if(__ballot(active) == 0ULL) {
+            if(exhausted) {
+                break;
+            }
+            continue;
+        }
+
+        // ---- one traversal step per active lane --------------------------------------------------------------------
+        if(active) {
+            bool need_pop = false;
+            if(cur == PT_REF_NONE) {
+                // walk finished: report
+                if(dest & PT_DEST_SHADOW) {
+                    vis[dest & ~PT_DEST_SHADOW] = 1u; // no visited leaf was closer than the light
+                }
+                else {
+                    hit[dest] = make_uint2(__float_as_uint(best_ref == PT_REF_NONE ? -1.0f : best_t), best_ref);
+                }
+                active = false;
+            }
+            else if(!(cur & PT_REF_LEAF)) {
+                float4 q0, q1, q2, q3;
+                if(cur < sc.n_lds_pairs) {
+                    const float4 *p = lds_pairs + 4 * cur;
+                    q0 = p[0];
+                    q1 = p[1];
+                    q2 = p[2];
+                    q3 = p[3];
+                }
+                else {
+                    const float4 *p = sc.pairs + 4 * (size_t)cur;
+                    q0 = p[0];
+                    q1 = p[1];
+                    q2 = p[2];
+                    q3 = p[3];
+                }
+                if(COUNT) {
+                    n_nodes++;
+                }
+                const float left_t = slab_test(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv);
+                const float right_t = slab_test(v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o, inv);
+                const uint32_t left_ref = __float_as_uint(q3.x);
+                const uint32_t right_ref = __float_as_uint(q3.y);
+                const bool left_close = left_t < right_t; // equal entry distances: right is "close" (scene.cpp:120-121)
+                const float close_t = fmin_std(left_t, right_t);
+                const float far_t = fmax_std(left_t, right_t);
+                const uint32_t close_ref = left_close ? left_ref : right_ref;
+                const uint32_t far_ref = left_close ? right_ref : left_ref;
+                const bool go_close = close_t >= 0.0f && close_t < t_max;
+                const bool go_far = far_t >= 0.0f && far_t < t_max;
+                if(go_close) {
+                    if(go_far) {
+                        const uint2 e = make_uint2(far_ref, __float_as_uint(far_t));
+                        if(sp < STACK_LDS) {
+                            lds_stack[sp * 256 + tid] = e;
+                        }
+                        else {
+                            my_spill[sp - STACK_LDS] = e;
+                        }
+                        sp++;
+                    }
+                    cur = close_ref;
+                }
+                else if(go_far) {
+                    cur = far_ref;
+                }
+                else {
+                    need_pop = true;
+                }
+            }
+            else {
+                // leaf: Object::getIntersection
+                const uint32_t idx = cur & PT_REF_INDEX;
+                float t;
+                if(cur & PT_REF_SPHERE) {
+                    const float4 s = sc.spheres[idx];
+                    t = sphere_intersect(v3(s.x, s.y, s.z), s.w, o, d);
+                }
+                else {
+                    float4 t0, t1, t2;
+                    if(idx < sc.n_lds_tris) {
+                        const float4 *p = lds_tris + 3 * idx;
+                        t0 = p[0];
+                        t1 = p[1];
+                        t2 = p[2];
+                    }
+                    else {
+                        const float4 *p = sc.tris + 3 * (size_t)idx;
+                        t0 = p[0];
+                        t1 = p[1];
+                        t2 = p[2];
+                    }
+                    const TriRec tr = tri_unpack(t0, t1, t2);
+                    t = tri_intersect(tr.a, tr.ab, tr.ac, (tr.obj_cull >> 31) != 0, o, d);
+                }
+                if(COUNT) {
+                    n_leaves++;
+                }
+                need_pop = true;
+                if(t >= 0.0f) {
+                    if((dest & PT_DEST_SHADOW) && t < thr) {
+                        vis[dest & ~PT_DEST_SHADOW] = 0u; // occluded (worker.cpp:86)
+                        active = false;
+                        need_pop = false;
+                    }
+                    else {
+                        if(best_ref == PT_REF_NONE || !(best_t < t)) {
+                            best_t = t;
+                            best_ref = cur;
+                        }
+                        t_max = fmin_std(t_max, t);
+                    }
+                }
+            }
+            if(need_pop) {
+                cur = PT_REF_NONE;
+                while(sp > 0) {
+                    sp--;
+                    const uint2 e = (sp < STACK_LDS) ? lds_stack[sp * 256 + tid] : my_spill[sp - STACK_LDS];
+                    if(__uint_as_float(e.y) < t_max) {
+                        cur = e.x;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+
+    if(COUNT) {
+        // one atomic per wave and counter
+        for(int off = 32; off > 0; off >>= 1) {
+            n_nodes += __shfl_down(n_nodes, off);
+            n_leaves += __shfl_down(n_leaves, off);
+            n_rays += __shfl_down(n_rays, off);
+            n_shadow += __shfl_down(n_shadow, off);
+        }
+        if(lane == 0) {
+            atomicAdd(&counters->node_visits, (unsigned long long)n_nodes);
+            atomicAdd(&counters->leaf_tests, (unsigned long long)n_leaves);
+            atomicAdd(&counters->rays, (unsigned long long)n_rays);
+            atomicAdd(&counters->shadow_rays, (unsigned long long)n_shadow);
+        }
+    }
+}
+
+// pt_intersect_batch: one closest-hit ray per input ray, destination = its index
+__global__ void pt_batch_rays_kernel(const float *__restrict__ rays6, uint32_t n, PtQueue q) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) {
+        return;
+    }
+    // shard s holds the contiguous chunk [s * per, (s + 1) * per)
+    const uint32_t per = (n + PT_SHARDS - 1) / PT_SHARDS;
+    const uint32_t s = i / per;
+    const uint32_t k = i - s * per;
+    const float *r = rays6 + 6 * (size_t)i;
+    q.ray_o[s * q.shard_capacity + k] = make_float4(r[0], r[1], r[2], 0.0f);
+    q.ray_d[s * q.shard_capacity + k] = make_float4(r[3], r[4], r[5], __uint_as_float(i));
+    if(k == 0) {
+        const uint32_t end = (s + 1) * per < n ? (s + 1) * per : n;
+        q.count[s] = end - s * per;
+        q.head[s] = 0;
+    }
+}
+
+template<int STACK_LDS>
+void launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters) {
+    hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, paths.hit, paths.vis, cfg.spill,
+                       cfg.spill_depth, counters);
+}
+
+} // namespace
+
+void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters) {
+    switch(cfg.stack_lds) {
+        case 8:
+            launch_trace<8>(stream, scene, queue, paths, cfg, counters);
+            break;
+        case 24:
+            launch_trace<24>(stream, scene, queue, paths, cfg, counters);
+            break;
+        default:
+            launch_trace<16>(stream, scene, queue, paths, cfg, counters);
+            break;
+    }
+}
+
+int pt_trace_blocks_per_cu(int stack_lds, size_t lds_bytes) {
+    int blocks = 0;
+    hipError_t err;
+    switch(stack_lds) {
+        case 8:
+            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<8, true>, 256, lds_bytes);
+            break;
+        case 24:
+            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<24, true>, 256, lds_bytes);
+            break;
+        default:
+            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<16, true>, 256, lds_bytes);
+            break;
+    }
+    if(err != hipSuccess || blocks < 1) {
+        blocks = 1;
+    }
+    return blocks;
+}
+
+void pt_launch_batch_rays(hipStream_t stream, const float *rays6, uint32_t n, PtQueue queue) {
+    if(n == 0) {
+        return;
+    }
+    hipLaunchKernelGGL(pt_batch_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rays6, n, queue);
+}

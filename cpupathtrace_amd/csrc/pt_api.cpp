@@ -341,6 +341,13 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     PtQueue q = make_queue(s);
     hipStream_t st = s->stream;
     PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters), st));
+    // no more workgroups than the rays one iteration can produce
+    PtTraceConfig trace_cfg = s->trace_cfg;
+    {
+        const uint64_t max_rays = static_cast<uint64_t>(n) * (1U + s->dev.n_lights + s->dev.n_object_samples);
+        const uint64_t blocks = (max_rays + 255) / 256;
+        trace_cfg.grid = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(trace_cfg.grid), blocks)));
+    }
 
     const bool timing = stats != nullptr;
     const int kEventPairs = 64;
@@ -382,7 +389,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
                 PT_HIP(hipEventRecord(ev[4 * pending + 1], st));
                 PT_HIP(hipEventRecord(ev[4 * pending + 2], st));
             }
-            pt_launch_trace(st, s->dev, q, P, s->trace_cfg, s->counters.ptr);
+            pt_launch_trace(st, s->dev, q, P, trace_cfg, s->counters.ptr);
             if(timing) {
                 PT_HIP(hipEventRecord(ev[4 * pending + 3], st));
                 if(++pending == kEventPairs) {
@@ -802,7 +809,9 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
     PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, 2 * PT_SHARDS * sizeof(uint32_t), st));
     PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters), st));
     pt_launch_batch_rays(st, s->batch_rays.ptr, n32, q);
-    pt_launch_trace(st, s->dev, q, P, s->trace_cfg, s->counters.ptr);
+    PtTraceConfig trace_cfg = s->trace_cfg;
+    trace_cfg.grid = static_cast<int>(std::max<uint32_t>(1U, std::min<uint32_t>(static_cast<uint32_t>(trace_cfg.grid), (n32 + 255U) / 256U)));
+    pt_launch_trace(st, s->dev, q, P, trace_cfg, s->counters.ptr);
     std::vector<uint2> hits(n);
     PT_HIP(hipMemcpyAsync(hits.data(), s->hit.ptr, n * sizeof(uint2), hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));

@@ -89,15 +89,18 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             uint32_t first = 0, avail = 0;
             while(!exhausted) {
                 const uint32_t count = q.count[shard];
-                uint32_t base = 0;
-                if(lane == 0) {
-                    base = atomicAdd(&q.head[shard], (uint32_t)n_idle);
-                }
-                base = __builtin_amdgcn_readfirstlane(base);
-                if(base < count) {
-                    first = shard * q.shard_capacity + base;
-                    avail = count - base;
-                    break;
+                // heads only grow: a (possibly stale) head at or past the end means the shard is drained, no atomic needed
+                if(__hip_atomic_load(&q.head[shard], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < count) {
+                    uint32_t base = 0;
+                    if(lane == 0) {
+                        base = atomicAdd(&q.head[shard], (uint32_t)n_idle);
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if(base < count) {
+                        first = shard * q.shard_capacity + base;
+                        avail = count - base;
+                        break;
+                    }
                 }
                 shard = (shard + 1) % PT_SHARDS;
                 if(++shards_tried >= PT_SHARDS) {

@@ -1,0 +1,81 @@
+"""Tile sharding of one frame over the GPUs of a node: the multi-GPU form of the reference's tile queue.
+
+The reference cuts a frame into <= 32x32 tiles and lets its worker threads pull them from one queue; tiles never talk to
+each other (src/worker.cpp:328-424).  Here every rank (one process per GPU, torch.distributed over RCCL) owns the tiles
+`tile_index % world == rank` of the same list, renders them with the replicated scene, and the only exchange is the
+gather of finished tiles to rank 0 at the end of a frame.  Because every pixel has its own engine seeded from
+(base_seed, x, y), the assembled frame is bit-identical for any number of ranks.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import binding
+
+
+def local_tiles(tiles, rank, world):
+    return tiles[rank::world]
+
+
+def pixel_indices(tiles, width):
+    """Row-major pixel indices (y * width + x) covered by `tiles`, tile after tile."""
+    parts = []
+    for t in tiles:
+        ys = np.arange(t["y"], t["y"] + t["h"], dtype=np.int64)[:, None]
+        xs = np.arange(t["x"], t["x"] + t["w"], dtype=np.int64)[None, :]
+        parts.append((ys * width + xs).ravel())
+    return np.concatenate(parts) if parts else np.zeros(0, np.int64)
+
+
+class ShardedJob:
+    """One frame (FrameRenderJob) whose tiles are spread over `world` ranks.
+
+    render_fn(tiles, image_tensor, want_stats) renders the given tiles into the (height, width, 4) float32 tensor on this
+    rank's device; the default calls the HIP library.  Tests pass their own to exercise the sharding on CPU/gloo."""
+
+    def __init__(self, scene, camera, options, rank, world, device, base_seed=1234, render_fn=None):
+        self.scene, self.camera, self.options = scene, camera, options
+        self.rank, self.world, self.device, self.base_seed = rank, world, device, base_seed
+        self.width, self.height = options["image_width"], options["image_height"]
+        self.tiles = binding.job_tiles(self.width, self.height) if scene is not None else _tiles_py(self.width, self.height)
+        self.mine = local_tiles(self.tiles, rank, world)
+        self.n_local_tiles = len(self.mine)
+        self.image = torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=device)
+        self.render_fn = render_fn or self._render_hip
+        if world > 1:
+            per_rank = [pixel_indices(local_tiles(self.tiles, r, world), self.width) for r in range(world)]
+            self.chunk = max(len(p) for p in per_rank)
+            self.my_index = torch.from_numpy(per_rank[rank]).to(device)
+            self.send = torch.zeros((self.chunk, 4), dtype=torch.float32, device=device)
+            if rank == 0:
+                self.all_index = [torch.from_numpy(p).to(device) for p in per_rank]
+                self.recv = [torch.zeros((self.chunk, 4), dtype=torch.float32, device=device) for _ in range(world)]
+
+    def _render_hip(self, tiles, image, want_stats):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        return self.scene.process_job_device(self.camera, self.options, image.data_ptr(), stream, base_seed=self.base_seed, tiles=tiles,
+                                             want_stats=want_stats)
+
+    def render(self, want_stats=False):
+        """Render this rank's tiles, then gather all tiles into rank 0's image.  Returns the render statistics of this rank."""
+        stats = self.render_fn(self.mine, self.image, want_stats)
+        if self.world > 1:
+            flat = self.image.view(-1, 4)
+            self.send[: len(self.my_index)] = flat[self.my_index]
+            dist.gather(self.send, self.recv if self.rank == 0 else None, dst=0)
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    idx = self.all_index[r]
+                    flat[idx] = self.recv[r][: len(idx)]
+        return stats
+
+
+def _tiles_py(width, height):
+    """processJob's tile list (reference src/worker.cpp:398-414) without loading the HIP library (CPU-only tests)."""
+    width, height = max(width, 0), max(height, 0)
+    if width == 0 or height == 0:
+        return np.zeros(0, dtype=binding.TILE_DTYPE)
+    ts = max(min(min(width, height) // 4, 32), 1)
+    out = [(tx * ts, ty * ts, min(width - tx * ts, ts), min(height - ty * ts, ts))
+           for ty in range((height + ts - 1) // ts) for tx in range((width + ts - 1) // ts)]
+    return np.array(out, dtype=binding.TILE_DTYPE)

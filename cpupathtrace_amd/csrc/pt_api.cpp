@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -155,7 +156,7 @@ struct pt_scene {
     DevBuf<PtCandidate> cand;
     DevBuf<uint2> hit;
     DevBuf<F4> q_ray_o, q_ray_d;
-    DevBuf<uint32_t> q_header; // count[8], head[8]
+    DevBuf<uint32_t> q_header; // count[8], head[8], each word on its own 256-byte line
     DevBuf<uint2> spill;
     DevBuf<PtDevCounters> counters;
     DevBuf<F4> image;
@@ -215,7 +216,7 @@ PtQueue make_queue(pt_scene *s) {
     q.ray_o = reinterpret_cast<float4 *>(s->q_ray_o.ptr);
     q.ray_d = reinterpret_cast<float4 *>(s->q_ray_d.ptr);
     q.count = s->q_header.ptr;
-    q.head = s->q_header.ptr + PT_SHARDS;
+    q.head = s->q_header.ptr + PT_SHARDS * PT_QSTRIDE;
     q.shard_capacity = s->shard_capacity;
     return q;
 }
@@ -244,7 +245,7 @@ int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot) {
     PT_HIP(s->hit.ensure(n));
     PT_HIP(s->q_ray_o.ensure(static_cast<size_t>(cap) * PT_SHARDS));
     PT_HIP(s->q_ray_d.ensure(static_cast<size_t>(cap) * PT_SHARDS));
-    PT_HIP(s->q_header.ensure(2 * PT_SHARDS));
+    PT_HIP(s->q_header.ensure(2 * PT_SHARDS * PT_QSTRIDE));
     PT_HIP(s->counters.ensure(1));
     s->shard_capacity = static_cast<uint32_t>(s->q_ray_o.count / PT_SHARDS);
     s->ws_slots = n;
@@ -271,6 +272,11 @@ int setup_trace(pt_scene *s) {
     cfg.spill_depth = s->tree.depth > static_cast<uint32_t>(stack_lds) ? s->tree.depth - static_cast<uint32_t>(stack_lds) : 1U;
     PT_HIP(s->spill.ensure(static_cast<size_t>(cfg.grid) * 256 * cfg.spill_depth));
     cfg.spill = s->spill.ptr;
+    cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 20), 1), 64);
+    if(env_int("PT_DEBUG", 0) != 0) {
+        std::fprintf(stderr, "[pt] trace config: grid %d (%d CUs x %d blocks), stack_lds %d, lds %zu B, spill depth %u, lds pairs %u, lds tris %u\n", cfg.grid,
+                     s->cu_count, per_cu, stack_lds, cfg.lds_bytes, cfg.spill_depth, s->dev.n_lds_pairs, s->dev.n_lds_tris);
+    }
     return PT_OK;
 }
 
@@ -380,7 +386,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     int pending = 0;
     for(;;) {
         for(int k = 0; k < check_every; k++) {
-            PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, 2 * PT_SHARDS * sizeof(uint32_t), st));
+            PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, 2 * PT_SHARDS * PT_QSTRIDE * sizeof(uint32_t), st));
             if(timing) {
                 PT_HIP(hipEventRecord(ev[4 * pending + 0], st));
             }
@@ -806,7 +812,7 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
     }
     hipStream_t st = s->stream;
     PT_HIP(hipMemcpyAsync(s->batch_rays.ptr, rays, 6 * n * sizeof(float), hipMemcpyHostToDevice, st));
-    PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, 2 * PT_SHARDS * sizeof(uint32_t), st));
+    PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, 2 * PT_SHARDS * PT_QSTRIDE * sizeof(uint32_t), st));
     PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters), st));
     pt_launch_batch_rays(st, s->batch_rays.ptr, n32, q);
     PtTraceConfig trace_cfg = s->trace_cfg;

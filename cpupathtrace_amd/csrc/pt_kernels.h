@@ -6,6 +6,8 @@
 
 #include "pt_types.h"
 
+#define PT_QSTRIDE 64 /* every queue counter sits alone in a 256-byte line: device-scope atomics on words that share a line serialise */
+#define PT_QCHUNK 256 /* rays a wavefront reserves per dequeue atomic */
 #define PT_SHARDS 8 /* ray-queue shards = XCDs; a workgroup appends to and first drains shard blockIdx.x % 8 */
 
 // Wavefront state of all streams in flight (structure of arrays, one element per stream slot).
@@ -41,8 +43,8 @@ struct PtPaths {
 struct PtQueue {
     float4 *ray_o;   // origin xyz, w = shadow threshold |to_light| - epsilon (worker.cpp:86) or unused
     float4 *ray_d;   // direction xyz, w = bits destination: bit 31 = shadow ray, low bits = slot (ext) or slot * PT_MAX_NEE + j
-    uint32_t *count; // [PT_SHARDS] rays appended
-    uint32_t *head;  // [PT_SHARDS] rays dequeued
+    uint32_t *count; // [PT_SHARDS * PT_QSTRIDE] rays appended to shard s at count[s * PT_QSTRIDE]
+    uint32_t *head;  // [PT_SHARDS * PT_QSTRIDE] rays dequeued from shard s at head[s * PT_QSTRIDE]
     uint32_t shard_capacity;
 };
 
@@ -55,6 +57,7 @@ struct PtTraceConfig {
     uint32_t spill_depth; // further entries per lane in HBM
     uint2 *spill;
     size_t lds_bytes;
+    int refill_idle;      // a wavefront refills from the queue once this many of its 64 lanes are idle
 };
 
 void pt_launch_init_tiles(hipStream_t stream, PtPaths paths, const int4 *tiles, const uint32_t *tile_offset, uint32_t n_tiles, uint64_t base_seed);

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
     uint32_t wave_base = 0;
     if(wave_total > 0) {
         if(lane == 0) {
-            wave_base = atomicAdd(&q.count[shard], wave_total);
+            wave_base = atomicAdd(&q.count[shard * PT_QSTRIDE], wave_total);
         }
         wave_base = __builtin_amdgcn_readfirstlane(wave_base);
     }

@@ -17,8 +17,9 @@
 //
 // How it maps to gfx950:
 //   * one ray per lane, 256-thread workgroups, persistent: a wavefront refills its idle lanes from the queue whenever at least
-//     PT_REFILL_IDLE lanes are idle (ballot + popcount + one atomic per refill; lane i takes the i-th fetched ray by
-//     prefix-popcount of the idle mask), so lanes that drew short traversals do not wait for the longest one;
+//     PT_REFILL_IDLE lanes are idle (ballot + popcount; lane i takes the i-th ray of the wave's reservation by
+//     prefix-popcount of the idle mask; one atomic reserves PT_QCHUNK rays), so lanes that drew short traversals do not
+//     wait for the longest one;
 //   * the queue has one shard per XCD: a workgroup drains shard blockIdx.x % 8 first (rays appended by shading workgroups
 //     of the same residue, i.e. neighbouring pixels share an L2), then steals from the others;
 //   * inner nodes are 64-byte records holding BOTH child boxes, so a traversal step is one 64-byte fetch (4 x dwordx4) per
@@ -36,15 +37,23 @@ using namespace ptd;
 
 namespace {
 
-struct TraceLds {
-    uint2 *stack;        // [stack_lds][256]
-    const float4 *pairs; // [n_lds_pairs * 4]
-    const float4 *tris;  // [n_lds_tris * 3]
-};
+// Explicit address spaces: a pointer that is "LDS or HBM depending on the index" makes hipcc fall back to flat_load (generic
+// addressing, split into odd dwordx3 pieces and routed through the texture path even for LDS); with typed pointers the two
+// sides stay ds_read_b128 and global_load_dwordx4.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+typedef const f4v __attribute__((address_space(3))) *lds_f4_cptr;
+typedef u2v __attribute__((address_space(3))) *lds_u2_ptr;
+typedef const f4v __attribute__((address_space(1))) *glb_f4_cptr;
+typedef u2v __attribute__((address_space(1))) *glb_u2_ptr;
+
+PT_D float4 to_f4(f4v v) {
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 template<int STACK_LDS, bool COUNT>
 __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, uint2 *__restrict__ hit, uint32_t *__restrict__ vis,
-                                                       uint2 *__restrict__ spill, uint32_t spill_depth, PtDevCounters *counters) {
+                                                       uint2 *__restrict__ spill, uint32_t spill_depth, int refill_idle, PtDevCounters *counters) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     uint2 *lds_stack = reinterpret_cast<uint2 *>(lds_raw);
     float4 *lds_pairs = reinterpret_cast<float4 *>(lds_raw + (size_t)STACK_LDS * 256 * sizeof(uint2));
@@ -62,7 +71,12 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     }
     __syncthreads();
 
-    uint2 *my_spill = spill + ((size_t)blockIdx.x * 256 + tid) * spill_depth;
+    glb_u2_ptr my_spill = (glb_u2_ptr)(spill + ((size_t)blockIdx.x * 256 + tid) * spill_depth);
+    lds_u2_ptr stack_l = (lds_u2_ptr)lds_stack;
+    lds_f4_cptr pairs_l = (lds_f4_cptr)lds_pairs;
+    lds_f4_cptr tris_l = (lds_f4_cptr)lds_tris;
+    glb_f4_cptr pairs_g = (glb_f4_cptr)sc.pairs;
+    glb_f4_cptr tris_g = (glb_f4_cptr)sc.tris;
 
     // wave-uniform queue cursor
     uint32_t shard = blockIdx.x % PT_SHARDS;
@@ -81,33 +95,41 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     int sp = 0;
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0;
 
+    // rays reserved by this wavefront and not yet handed to a lane (wave-uniform)
+    uint32_t res_next = 0, res_end = 0;
+
     for(;;) {
         // ---- refill idle lanes -------------------------------------------------------------------------------------
         const unsigned long long idle_mask = __ballot(!active);
         const int n_idle = __popcll(idle_mask);
-        if(!exhausted && n_idle >= PT_REFILL_IDLE) {
-            uint32_t first = 0, avail = 0;
-            while(!exhausted) {
-                const uint32_t count = q.count[shard];
-                // heads only grow: a (possibly stale) head at or past the end means the shard is drained, no atomic needed
-                if(__hip_atomic_load(&q.head[shard], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < count) {
-                    uint32_t base = 0;
-                    if(lane == 0) {
-                        base = atomicAdd(&q.head[shard], (uint32_t)n_idle);
+        if(n_idle >= refill_idle && (res_next < res_end || !exhausted)) {
+            if(res_next >= res_end) {
+                // reserve the next PT_QCHUNK rays: own shard first, then the others
+                while(!exhausted) {
+                    const uint32_t count = q.count[shard * PT_QSTRIDE];
+                    // heads only grow: a (possibly stale) head at or past the end means the shard is drained, no atomic needed
+                    if(__hip_atomic_load(&q.head[shard * PT_QSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < count) {
+                        uint32_t base = 0;
+                        if(lane == 0) {
+                            base = atomicAdd(&q.head[shard * PT_QSTRIDE], (uint32_t)PT_QCHUNK);
+                        }
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if(base < count) {
+                            res_next = shard * q.shard_capacity + base;
+                            res_end = res_next + (count - base < PT_QCHUNK ? count - base : (uint32_t)PT_QCHUNK);
+                            break;
+                        }
                     }
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if(base < count) {
-                        first = shard * q.shard_capacity + base;
-                        avail = count - base;
-                        break;
+                    shard = (shard + 1) % PT_SHARDS;
+                    if(++shards_tried >= PT_SHARDS) {
+                        exhausted = true;
                     }
-                }
-                shard = (shard + 1) % PT_SHARDS;
-                if(++shards_tried >= PT_SHARDS) {
-                    exhausted = true;
                 }
             }
-            if(!exhausted && !active) {
+            const uint32_t avail = res_end - res_next;
+            const uint32_t first = res_next;
+            res_next += avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
+            if(!active) {
                 const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
                 if(rank < avail) {
                     const float4 ro = q.ray_o[first + rank];
@@ -140,7 +162,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             }
         }
         if(__ballot(active) == 0ULL) {
-            if(exhausted) {
+            if(exhausted && res_next >= res_end) {
                 break;
             }
             continue;
@@ -162,18 +184,18 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             else if(!(cur & PT_REF_LEAF)) {
                 float4 q0, q1, q2, q3;
                 if(cur < sc.n_lds_pairs) {
-                    const float4 *p = lds_pairs + 4 * cur;
-                    q0 = p[0];
-                    q1 = p[1];
-                    q2 = p[2];
-                    q3 = p[3];
+                    lds_f4_cptr p = pairs_l + 4 * cur;
+                    q0 = to_f4(p[0]);
+                    q1 = to_f4(p[1]);
+                    q2 = to_f4(p[2]);
+                    q3 = to_f4(p[3]);
                 }
                 else {
-                    const float4 *p = sc.pairs + 4 * (size_t)cur;
-                    q0 = p[0];
-                    q1 = p[1];
-                    q2 = p[2];
-                    q3 = p[3];
+                    glb_f4_cptr p = pairs_g + 4 * (size_t)cur;
+                    q0 = to_f4(p[0]);
+                    q1 = to_f4(p[1]);
+                    q2 = to_f4(p[2]);
+                    q3 = to_f4(p[3]);
                 }
                 if(COUNT) {
                     n_nodes++;
@@ -192,11 +214,12 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 if(go_close) {
                     if(go_far) {
                         const uint2 e = make_uint2(far_ref, __float_as_uint(far_t));
+                        const u2v ev = {e.x, e.y};
                         if(sp < STACK_LDS) {
-                            lds_stack[sp * 256 + tid] = e;
+                            stack_l[sp * 256 + tid] = ev;
                         }
                         else {
-                            my_spill[sp - STACK_LDS] = e;
+                            my_spill[sp - STACK_LDS] = ev;
                         }
                         sp++;
                     }
@@ -220,16 +243,16 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 else {
                     float4 t0, t1, t2;
                     if(idx < sc.n_lds_tris) {
-                        const float4 *p = lds_tris + 3 * idx;
-                        t0 = p[0];
-                        t1 = p[1];
-                        t2 = p[2];
+                        lds_f4_cptr p = tris_l + 3 * idx;
+                        t0 = to_f4(p[0]);
+                        t1 = to_f4(p[1]);
+                        t2 = to_f4(p[2]);
                     }
                     else {
-                        const float4 *p = sc.tris + 3 * (size_t)idx;
-                        t0 = p[0];
-                        t1 = p[1];
-                        t2 = p[2];
+                        glb_f4_cptr p = tris_g + 3 * (size_t)idx;
+                        t0 = to_f4(p[0]);
+                        t1 = to_f4(p[1]);
+                        t2 = to_f4(p[2]);
                     }
                     const TriRec tr = tri_unpack(t0, t1, t2);
                     t = tri_intersect(tr.a, tr.ab, tr.ac, (tr.obj_cull >> 31) != 0, o, d);
@@ -257,7 +280,13 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 cur = PT_REF_NONE;
                 while(sp > 0) {
                     sp--;
-                    const uint2 e = (sp < STACK_LDS) ? lds_stack[sp * 256 + tid] : my_spill[sp - STACK_LDS];
+                    u2v e;
+                    if(sp < STACK_LDS) {
+                        e = stack_l[sp * 256 + tid];
+                    }
+                    else {
+                        e = my_spill[sp - STACK_LDS];
+                    }
                     if(__uint_as_float(e.y) < t_max) {
                         cur = e.x;
                         break;
@@ -299,15 +328,15 @@ __global__ void pt_batch_rays_kernel(const float *__restrict__ rays6, uint32_t n
     q.ray_d[s * q.shard_capacity + k] = make_float4(r[3], r[4], r[5], __uint_as_float(i));
     if(k == 0) {
         const uint32_t end = (s + 1) * per < n ? (s + 1) * per : n;
-        q.count[s] = end - s * per;
-        q.head[s] = 0;
+        q.count[s * PT_QSTRIDE] = end - s * per;
+        q.head[s * PT_QSTRIDE] = 0;
     }
 }
 
 template<int STACK_LDS>
 void launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters) {
     hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, paths.hit, paths.vis, cfg.spill,
-                       cfg.spill_depth, counters);
+                       cfg.spill_depth, cfg.refill_idle, counters);
 }
 
 } // namespace

@@ -69,7 +69,10 @@ def cpu_baseline(sc, cam, opt, seconds_target):
     """The reference itself (oracle/_ref, kind "reference") or, if that was not built, the C restatement (kind "port"),
     timed on this host's cores on a bounded random subset of the SAME frame's pixels (same scene, same spp)."""
     import oracle
-    threads = max((os.cpu_count() or 2) - 1, 1)  # the reference's default worker count, src/worker.cpp:366
+    # the reference's default worker count is hardware_concurrency() - 1 (src/worker.cpp:366); a GPU box grants this job
+    # a 16-core share of the host, so the count is taken from that share, not from the machine's 256 logical CPUs
+    share = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2), int(os.environ.get("PT_CPU_SHARE", "16")))
+    threads = max(share - 1, 1)
     try:
         chk, kind = oracle.Checker("ref", ndebug=True), "reference"
     except (FileNotFoundError, OSError):
@@ -107,7 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dragon")
     ap.add_argument("--size", type=int, default=1024, help="pixels per side per GPU")
-    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--mesh-n", type=int, default=1900, help="stand-in mesh resolution (nu = nv); 1900 -> 7.2 M triangles")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)

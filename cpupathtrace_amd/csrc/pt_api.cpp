@@ -265,17 +265,19 @@ int setup_trace(pt_scene *s) {
         stack_lds = 16;
     }
     cfg.stack_lds = stack_lds;
+    cfg.lds_mode = (s->dev.n_lds_pairs == 0 && s->dev.n_lds_tris == 0) ? 0 : ((s->dev.n_lds_pairs == s->dev.n_pairs && s->dev.n_lds_tris == s->dev.n_tris) ? 2 : 1);
     cfg.lds_bytes = static_cast<size_t>(stack_lds) * 256 * sizeof(uint2) + static_cast<size_t>(s->dev.n_lds_pairs) * 64 + static_cast<size_t>(s->dev.n_lds_tris) * 48;
-    const int per_cu = pt_trace_blocks_per_cu(stack_lds, cfg.lds_bytes);
+    const int per_cu = pt_trace_blocks_per_cu(stack_lds, cfg.lds_mode, cfg.lds_bytes);
     const int limit = env_int("PT_TRACE_BLOCKS_PER_CU", 0);
     cfg.grid = s->cu_count * ((limit > 0 && limit < per_cu) ? limit : per_cu);
     cfg.spill_depth = s->tree.depth > static_cast<uint32_t>(stack_lds) ? s->tree.depth - static_cast<uint32_t>(stack_lds) : 1U;
     PT_HIP(s->spill.ensure(static_cast<size_t>(cfg.grid) * 256 * cfg.spill_depth));
     cfg.spill = s->spill.ptr;
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 20), 1), 64);
+    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 1), 1), 64);
     if(env_int("PT_DEBUG", 0) != 0) {
-        std::fprintf(stderr, "[pt] trace config: grid %d (%d CUs x %d blocks), stack_lds %d, lds %zu B, spill depth %u, lds pairs %u, lds tris %u\n", cfg.grid,
-                     s->cu_count, per_cu, stack_lds, cfg.lds_bytes, cfg.spill_depth, s->dev.n_lds_pairs, s->dev.n_lds_tris);
+        std::fprintf(stderr, "[pt] trace config: grid %d (%d CUs x %d blocks), stack_lds %d, lds mode %d, lds %zu B, spill depth %u, lds pairs %u, lds tris %u\n", cfg.grid,
+                     s->cu_count, per_cu, stack_lds, cfg.lds_mode, cfg.lds_bytes, cfg.spill_depth, s->dev.n_lds_pairs, s->dev.n_lds_tris);
     }
     return PT_OK;
 }
@@ -577,7 +579,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     if(s->tree.depth > PT_MAX_DEPTH) {
         return fail(PT_ERR_UNSUPPORTED, "BVH deeper than 128 levels");
     }
-    ptb::FlatBvh flat = ptb::flatten_breadth_first(s->tree, leaf_ref);
+    ptb::FlatBvh flat = ptb::flatten_breadth_first(s->tree, leaf_ref, env_int("PT_ALIGN_SIBLINGS", 1) != 0);
 
     // ---- triangle / sphere / material records --------------------------------------------------------------------------------
     std::vector<F4> tris(3 * static_cast<size_t>(d->n_triangles)), nrm(3 * static_cast<size_t>(d->n_triangles));
@@ -729,11 +731,18 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     dev.n_lights = d->n_point_lights;
     dev.n_emis = s->n_emissive;
     dev.n_object_samples = static_cast<uint32_t>(object_sample_count);
-    // LDS staging: the breadth-first top of the tree, and the triangle records of small scenes
-    const uint32_t lds_pairs_cap = static_cast<uint32_t>(std::max(env_int("PT_LDS_PAIRS", 255), 0));
-    const uint32_t lds_tris_cap = static_cast<uint32_t>(std::max(env_int("PT_LDS_TRIS", 128), 0));
-    dev.n_lds_pairs = std::min(flat.n_pairs, lds_pairs_cap);
-    dev.n_lds_tris = d->n_triangles <= lds_tris_cap ? d->n_triangles : 0U;
+    // LDS staging: a scene whose whole tree and triangle records fit in 24 KiB lives in LDS entirely; for larger scenes the
+    // traversal kernel is bound by instruction issue, not by node latency, and an LDS copy of the top of the tree only costs
+    // occupancy (measured: profiles/), so it is off unless PT_LDS_PAIRS asks for it.
+    const size_t small_bytes = static_cast<size_t>(flat.n_pairs) * 64 + static_cast<size_t>(d->n_triangles) * 48;
+    if(small_bytes <= 24 * 1024 && env_int("PT_LDS_SMALL", 1) != 0) {
+        dev.n_lds_pairs = flat.n_pairs;
+        dev.n_lds_tris = d->n_triangles;
+    }
+    else {
+        dev.n_lds_pairs = std::min(flat.n_pairs, static_cast<uint32_t>(std::max(env_int("PT_LDS_PAIRS", 0), 0)));
+        dev.n_lds_tris = 0;
+    }
 
     int rc = setup_trace(s.get());
     if(rc != PT_OK) {

@@ -46,7 +46,7 @@ struct FlatBvh {
 };
 
 // leaf_ref[i] = reference word of object i (PT_REF_LEAF | kind bit | typed index)
-FlatBvh flatten_breadth_first(const Tree &tree, const std::vector<uint32_t> &leaf_ref);
+FlatBvh flatten_breadth_first(const Tree &tree, const std::vector<uint32_t> &leaf_ref, bool align_siblings);
 
 } // namespace ptb
 

@@ -58,6 +58,8 @@ struct PtTraceConfig {
     uint2 *spill;
     size_t lds_bytes;
     int refill_idle;      // a wavefront refills from the queue once this many of its 64 lanes are idle
+    int leaf_min;         // leaf tests run once this many lanes stand on a leaf (or no lane has an inner node left)
+    int lds_mode;         // 0: no LDS staging, 1: top of the tree in LDS, 2: whole tree + triangles in LDS
 };
 
 void pt_launch_init_tiles(hipStream_t stream, PtPaths paths, const int4 *tiles, const uint32_t *tile_offset, uint32_t n_tiles, uint64_t base_seed);
@@ -66,7 +68,7 @@ void pt_launch_shade(hipStream_t stream, const PtDevScene &scene, const PtDevCam
                      float4 *image, PtDevCounters *counters);
 void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters);
 void pt_launch_batch_rays(hipStream_t stream, const float *rays6, uint32_t n, PtQueue queue);
-int pt_trace_blocks_per_cu(int stack_lds, size_t lds_bytes);
+int pt_trace_blocks_per_cu(int stack_lds, int lds_mode, size_t lds_bytes);
 
 uint64_t pt_host_pixel_seed(uint64_t base_seed, int32_t x, int32_t y);
 

@@ -51,9 +51,31 @@ PT_D float4 to_f4(f4v v) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-template<int STACK_LDS, bool COUNT>
+// slab test of the device walk: bounding_box.cpp:38-73 with std::min/std::max replaced by v_min_f32/v_max_f32.
+// The two differ only for NaN operands (the reference asserts there are none, bounding_box.cpp:60-61) and in the sign of a
+// zero result, and every use of the returned distance is an ordered comparison, for which -0 and +0 are the same value.
+PT_D float slab_walk(V3 lo, V3 hi, V3 o, V3 inv) {
+    const float t1 = (lo.x - o.x) * inv.x;
+    const float t2 = (hi.x - o.x) * inv.x;
+    const float t3 = (lo.y - o.y) * inv.y;
+    const float t4 = (hi.y - o.y) * inv.y;
+    const float t5 = (lo.z - o.z) * inv.z;
+    const float t6 = (hi.z - o.z) * inv.z;
+    const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1, t2), __builtin_fminf(t3, t4)), __builtin_fminf(t5, t6));
+    const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1, t2), __builtin_fmaxf(t3, t4)), __builtin_fmaxf(t5, t6));
+    if(t_max < 0.0f || t_min > t_max) {
+        return -1.0f;
+    }
+    return t_min < 0.0f ? 0.0f : t_min; // origin inside: t_min < 0 <= t_max (bounding_box.cpp:68-70)
+}
+
+// LDS_MODE: 0 = every node/triangle record comes from HBM/L2 (large scenes: the LDS copy only costs occupancy),
+//           1 = records with index < n_lds_* come from LDS, the rest from HBM (breadth-first top of the tree),
+//           2 = the whole tree and all triangles are in LDS (small scenes).
+template<int STACK_LDS, int LDS_MODE, bool COUNT>
 __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, uint2 *__restrict__ hit, uint32_t *__restrict__ vis,
-                                                       uint2 *__restrict__ spill, uint32_t spill_depth, int refill_idle, PtDevCounters *counters) {
+                                                       uint2 *__restrict__ spill, uint32_t spill_depth, int refill_idle, int leaf_min,
+                                                       PtDevCounters *counters) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     uint2 *lds_stack = reinterpret_cast<uint2 *>(lds_raw);
     float4 *lds_pairs = reinterpret_cast<float4 *>(lds_raw + (size_t)STACK_LDS * 256 * sizeof(uint2));
@@ -62,14 +84,16 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
-    // stage the top of the tree (and the triangles of small scenes) in LDS
-    for(uint32_t i = tid; i < 4 * sc.n_lds_pairs; i += 256) {
-        lds_pairs[i] = sc.pairs[i];
+    if(LDS_MODE != 0) {
+        // stage the top of the tree (and the triangles of small scenes) in LDS
+        for(uint32_t i = tid; i < 4 * sc.n_lds_pairs; i += 256) {
+            lds_pairs[i] = sc.pairs[i];
+        }
+        for(uint32_t i = tid; i < 3 * sc.n_lds_tris; i += 256) {
+            lds_tris[i] = sc.tris[i];
+        }
+        __syncthreads();
     }
-    for(uint32_t i = tid; i < 3 * sc.n_lds_tris; i += 256) {
-        lds_tris[i] = sc.tris[i];
-    }
-    __syncthreads();
 
     glb_u2_ptr my_spill = (glb_u2_ptr)(spill + ((size_t)blockIdx.x * 256 + tid) * spill_depth);
     lds_u2_ptr stack_l = (lds_u2_ptr)lds_stack;
@@ -82,12 +106,14 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     uint32_t shard = blockIdx.x % PT_SHARDS;
     uint32_t shards_tried = 0;
     bool exhausted = false;
+    // rays reserved by this wavefront and not yet handed to a lane (wave-uniform)
+    uint32_t res_next = 0, res_end = 0;
 
-    // per-lane traversal state
+    // per-lane traversal state; cur == PT_REF_NONE on an active lane means "walk finished, result not yet written"
     bool active = false;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 0), inv = v3(0, 0, 0);
-    float thr = 0.0f;     // shadow threshold
-    uint32_t dest = 0;    // destination word of the ray
+    float thr = 0.0f;  // shadow threshold
+    uint32_t dest = 0; // destination word of the ray
     float best_t = 0.0f;
     uint32_t best_ref = PT_REF_NONE;
     float t_max = FLT_MAX;
@@ -95,11 +121,19 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     int sp = 0;
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0;
 
-    // rays reserved by this wavefront and not yet handed to a lane (wave-uniform)
-    uint32_t res_next = 0, res_end = 0;
-
     for(;;) {
-        // ---- refill idle lanes -------------------------------------------------------------------------------------
+        // ---- 1. retire finished walks ----------------------------------------------------------------------------------
+        if(active && cur == PT_REF_NONE) {
+            if(dest & PT_DEST_SHADOW) {
+                vis[dest & ~PT_DEST_SHADOW] = 1u; // no visited leaf was closer than the light
+            }
+            else {
+                hit[dest] = make_uint2(__float_as_uint(best_ref == PT_REF_NONE ? -1.0f : best_t), best_ref);
+            }
+            active = false;
+        }
+
+        // ---- 2. refill idle lanes ----------------------------------------------------------------------------------------
         const unsigned long long idle_mask = __ballot(!active);
         const int n_idle = __popcll(idle_mask);
         if(n_idle >= refill_idle && (res_next < res_end || !exhausted)) {
@@ -152,7 +186,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                         // Scene::getIntersection: root box first (scene.cpp:211-219)
                         cur = PT_REF_NONE;
                         if(sc.root_ref != PT_REF_NONE) {
-                            const float t_root = slab_test(ld3(sc.root_lo), ld3(sc.root_hi), o, inv);
+                            const float t_root = slab_walk(ld3(sc.root_lo), ld3(sc.root_hi), o, inv);
                             if(t_root >= 0.0f) {
                                 cur = sc.root_ref;
                             }
@@ -168,22 +202,17 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             continue;
         }
 
-        // ---- one traversal step per active lane --------------------------------------------------------------------
-        if(active) {
-            bool need_pop = false;
-            if(cur == PT_REF_NONE) {
-                // walk finished: report
-                if(dest & PT_DEST_SHADOW) {
-                    vis[dest & ~PT_DEST_SHADOW] = 1u; // no visited leaf was closer than the light
-                }
-                else {
-                    hit[dest] = make_uint2(__float_as_uint(best_ref == PT_REF_NONE ? -1.0f : best_t), best_ref);
-                }
-                active = false;
+        // ---- 3. inner nodes: a burst of steps for the lanes standing on an inner node -----------------------------------------
+        // Lanes that reach a leaf wait (their order of visits is unchanged) until enough of them can share the leaf code.
+#pragma unroll 1
+        for(int burst = 0; burst < 4; burst++) {
+            const bool on_inner = active && !(cur & PT_REF_LEAF);
+            if(__ballot(on_inner) == 0ULL) {
+                break;
             }
-            else if(!(cur & PT_REF_LEAF)) {
+            if(on_inner) {
                 float4 q0, q1, q2, q3;
-                if(cur < sc.n_lds_pairs) {
+                if(LDS_MODE == 2 || (LDS_MODE == 1 && cur < sc.n_lds_pairs)) {
                     lds_f4_cptr p = pairs_l + 4 * cur;
                     q0 = to_f4(p[0]);
                     q1 = to_f4(p[1]);
@@ -200,21 +229,20 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 if(COUNT) {
                     n_nodes++;
                 }
-                const float left_t = slab_test(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv);
-                const float right_t = slab_test(v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o, inv);
+                const float left_t = slab_walk(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv);
+                const float right_t = slab_walk(v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o, inv);
                 const uint32_t left_ref = __float_as_uint(q3.x);
                 const uint32_t right_ref = __float_as_uint(q3.y);
                 const bool left_close = left_t < right_t; // equal entry distances: right is "close" (scene.cpp:120-121)
-                const float close_t = fmin_std(left_t, right_t);
-                const float far_t = fmax_std(left_t, right_t);
+                const float close_t = left_close ? left_t : right_t;
+                const float far_t = left_close ? right_t : left_t;
                 const uint32_t close_ref = left_close ? left_ref : right_ref;
                 const uint32_t far_ref = left_close ? right_ref : left_ref;
                 const bool go_close = close_t >= 0.0f && close_t < t_max;
                 const bool go_far = far_t >= 0.0f && far_t < t_max;
                 if(go_close) {
                     if(go_far) {
-                        const uint2 e = make_uint2(far_ref, __float_as_uint(far_t));
-                        const u2v ev = {e.x, e.y};
+                        const u2v ev = {far_ref, __float_as_uint(far_t)};
                         if(sp < STACK_LDS) {
                             stack_l[sp * 256 + tid] = ev;
                         }
@@ -229,11 +257,31 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                     cur = far_ref;
                 }
                 else {
-                    need_pop = true;
+                    // pop: the first parked node whose entry distance is still below t_max
+                    cur = PT_REF_NONE;
+                    while(sp > 0) {
+                        sp--;
+                        u2v e;
+                        if(sp < STACK_LDS) {
+                            e = stack_l[sp * 256 + tid];
+                        }
+                        else {
+                            e = my_spill[sp - STACK_LDS];
+                        }
+                        if(__uint_as_float(e.y) < t_max) {
+                            cur = e.x;
+                            break;
+                        }
+                    }
                 }
             }
-            else {
-                // leaf: Object::getIntersection
+        }
+
+        // ---- 4. leaves: Object::getIntersection for the lanes standing on a leaf ------------------------------------------------
+        const bool on_leaf = active && (cur & PT_REF_LEAF) && cur != PT_REF_NONE;
+        const unsigned long long leaf_mask = __ballot(on_leaf);
+        if(leaf_mask != 0ULL && (__popcll(leaf_mask) >= leaf_min || __ballot(active && !(cur & PT_REF_LEAF)) == 0ULL)) {
+            if(on_leaf) {
                 const uint32_t idx = cur & PT_REF_INDEX;
                 float t;
                 if(cur & PT_REF_SPHERE) {
@@ -242,7 +290,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 }
                 else {
                     float4 t0, t1, t2;
-                    if(idx < sc.n_lds_tris) {
+                    if(LDS_MODE == 2 || (LDS_MODE == 1 && idx < sc.n_lds_tris)) {
                         lds_f4_cptr p = tris_l + 3 * idx;
                         t0 = to_f4(p[0]);
                         t1 = to_f4(p[1]);
@@ -260,12 +308,10 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 if(COUNT) {
                     n_leaves++;
                 }
-                need_pop = true;
+                bool occluded = false;
                 if(t >= 0.0f) {
                     if((dest & PT_DEST_SHADOW) && t < thr) {
-                        vis[dest & ~PT_DEST_SHADOW] = 0u; // occluded (worker.cpp:86)
-                        active = false;
-                        need_pop = false;
+                        occluded = true; // worker.cpp:86: a hit closer than the light
                     }
                     else {
                         if(best_ref == PT_REF_NONE || !(best_t < t)) {
@@ -275,21 +321,25 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                         t_max = fmin_std(t_max, t);
                     }
                 }
-            }
-            if(need_pop) {
-                cur = PT_REF_NONE;
-                while(sp > 0) {
-                    sp--;
-                    u2v e;
-                    if(sp < STACK_LDS) {
-                        e = stack_l[sp * 256 + tid];
-                    }
-                    else {
-                        e = my_spill[sp - STACK_LDS];
-                    }
-                    if(__uint_as_float(e.y) < t_max) {
-                        cur = e.x;
-                        break;
+                if(occluded) {
+                    vis[dest & ~PT_DEST_SHADOW] = 0u;
+                    active = false;
+                }
+                else {
+                    cur = PT_REF_NONE;
+                    while(sp > 0) {
+                        sp--;
+                        u2v e;
+                        if(sp < STACK_LDS) {
+                            e = stack_l[sp * 256 + tid];
+                        }
+                        else {
+                            e = my_spill[sp - STACK_LDS];
+                        }
+                        if(__uint_as_float(e.y) < t_max) {
+                            cur = e.x;
+                            break;
+                        }
                     }
                 }
             }
@@ -333,10 +383,43 @@ __global__ void pt_batch_rays_kernel(const float *__restrict__ rays6, uint32_t n
     }
 }
 
-template<int STACK_LDS>
+template<int STACK_LDS, int LDS_MODE>
 void launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters) {
-    hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, paths.hit, paths.vis, cfg.spill,
-                       cfg.spill_depth, cfg.refill_idle, counters);
+    hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, LDS_MODE, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, paths.hit, paths.vis,
+                       cfg.spill, cfg.spill_depth, cfg.refill_idle, cfg.leaf_min, counters);
+}
+
+template<int STACK_LDS>
+void launch_trace_mode(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters) {
+    switch(cfg.lds_mode) {
+        case 0:
+            launch_trace<STACK_LDS, 0>(stream, scene, queue, paths, cfg, counters);
+            break;
+        case 2:
+            launch_trace<STACK_LDS, 2>(stream, scene, queue, paths, cfg, counters);
+            break;
+        default:
+            launch_trace<STACK_LDS, 1>(stream, scene, queue, paths, cfg, counters);
+            break;
+    }
+}
+
+template<int STACK_LDS>
+int occupancy_mode(int lds_mode, size_t lds_bytes) {
+    int blocks = 0;
+    hipError_t err;
+    switch(lds_mode) {
+        case 0:
+            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<STACK_LDS, 0, true>, 256, lds_bytes);
+            break;
+        case 2:
+            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<STACK_LDS, 2, true>, 256, lds_bytes);
+            break;
+        default:
+            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<STACK_LDS, 1, true>, 256, lds_bytes);
+            break;
+    }
+    return (err != hipSuccess || blocks < 1) ? 1 : blocks;
 }
 
 } // namespace
@@ -344,35 +427,26 @@ void launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, Pt
 void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters) {
     switch(cfg.stack_lds) {
         case 8:
-            launch_trace<8>(stream, scene, queue, paths, cfg, counters);
+            launch_trace_mode<8>(stream, scene, queue, paths, cfg, counters);
             break;
         case 24:
-            launch_trace<24>(stream, scene, queue, paths, cfg, counters);
+            launch_trace_mode<24>(stream, scene, queue, paths, cfg, counters);
             break;
         default:
-            launch_trace<16>(stream, scene, queue, paths, cfg, counters);
+            launch_trace_mode<16>(stream, scene, queue, paths, cfg, counters);
             break;
     }
 }
 
-int pt_trace_blocks_per_cu(int stack_lds, size_t lds_bytes) {
-    int blocks = 0;
-    hipError_t err;
+int pt_trace_blocks_per_cu(int stack_lds, int lds_mode, size_t lds_bytes) {
     switch(stack_lds) {
         case 8:
-            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<8, true>, 256, lds_bytes);
-            break;
+            return occupancy_mode<8>(lds_mode, lds_bytes);
         case 24:
-            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<24, true>, 256, lds_bytes);
-            break;
+            return occupancy_mode<24>(lds_mode, lds_bytes);
         default:
-            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<16, true>, 256, lds_bytes);
-            break;
+            return occupancy_mode<16>(lds_mode, lds_bytes);
     }
-    if(err != hipSuccess || blocks < 1) {
-        blocks = 1;
-    }
-    return blocks;
 }
 
 void pt_launch_batch_rays(hipStream_t stream, const float *rays6, uint32_t n, PtQueue queue) {

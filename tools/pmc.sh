@@ -6,12 +6,10 @@ i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $group --output-format csv -d "$out/pass$i" -- "$@" > "$out.pass$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$out.pass$i.log"; }
+  timeout -k 5 ${PMC_TIMEOUT:-150} rocprofv3 --pmc $group --output-format csv -d "$out/pass$i" -- "$@" > "$out.pass$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$out.pass$i.log"; }
   echo "pass $i done: $group"
 done <<'GROUPS'
-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM
-SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_ACTIVE_INST_LDS
-TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum GRBM_GUI_ACTIVE
+GRBM_GUI_ACTIVE GRBM_TA_BUSY
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_TCR_TCP_STALL_CYCLES_sum
 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum

@@ -20,6 +20,8 @@
 #include "pt_bvh.h"
 #include "pt_kernels.h"
 
+#define PT_MAX_GROUPS 8 /* independent slices of the streams pipelined on separate HIP streams */
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -163,13 +165,27 @@ struct pt_scene {
     DevBuf<int4> tiles;
     DevBuf<uint32_t> tile_offset;
     DevBuf<float> batch_rays;
-    uint32_t shard_capacity = 0;
+    DevBuf<uint32_t> walk_hist;
+    // suspended walks: two pools per group
+    DevBuf<F4> carry_o, carry_d;
+    DevBuf<uint4> carry_state;
+    DevBuf<uint32_t> carry_sp, carry_header;
+    DevBuf<uint2> carry_stack;
+    uint32_t carry_cap = 0; // per pool
+    uint32_t shard_capacity = 0;   // per group
+    uint32_t ws_groups = 1;        // groups the queue / spill / counter buffers are sized for
     PtTraceConfig trace_cfg{};
-    PtDevCounters *host_counters = nullptr; // pinned
+    PtDevCounters *host_counters = nullptr; // pinned, PT_MAX_GROUPS entries
+    hipStream_t group_stream[PT_MAX_GROUPS] = {};
 
     ~pt_scene() {
         if(host_counters != nullptr) {
             (void)hipHostFree(host_counters);
+        }
+        for(hipStream_t gs : group_stream) {
+            if(gs != nullptr) {
+                (void)hipStreamDestroy(gs);
+            }
         }
         if(stream != nullptr) {
             (void)hipStreamDestroy(stream);
@@ -188,42 +204,62 @@ int device_count_quiet() {
     return n;
 }
 
-PtPaths make_paths(pt_scene *s, uint32_t n) {
+// view of the slots [start, start + n) of the workspace
+PtPaths make_paths(pt_scene *s, uint32_t n, uint32_t start = 0) {
     PtPaths P{};
     P.n = n;
-    P.rect = s->rect.ptr;
-    P.rng = s->rng.ptr;
-    P.cursor = s->cursor.ptr;
-    P.flags = s->flags.ptr;
-    P.ray_o = reinterpret_cast<float4 *>(s->ray_o.ptr);
-    P.ray_d = reinterpret_cast<float4 *>(s->ray_d.ptr);
-    P.spectrum = reinterpret_cast<float4 *>(s->spectrum.ptr);
-    P.out = reinterpret_cast<float4 *>(s->out.ptr);
-    P.divisor = s->divisor.ptr;
-    P.bounce_pd = s->bounce_pd.ptr;
-    P.path_length = s->path_length.ptr;
-    P.nee = reinterpret_cast<float4 *>(s->nee.ptr);
-    P.nee_mask = s->nee_mask.ptr;
-    P.est = s->est.ptr;
-    P.cand = s->cand.ptr;
-    P.hit = s->hit.ptr;
-    P.vis = s->vis.ptr;
+    P.rect = s->rect.ptr + start;
+    P.rng = s->rng.ptr + start;
+    P.cursor = s->cursor.ptr + start;
+    P.flags = s->flags.ptr + start;
+    P.ray_o = reinterpret_cast<float4 *>(s->ray_o.ptr) + start;
+    P.ray_d = reinterpret_cast<float4 *>(s->ray_d.ptr) + start;
+    P.spectrum = reinterpret_cast<float4 *>(s->spectrum.ptr) + start;
+    P.out = reinterpret_cast<float4 *>(s->out.ptr) + start;
+    P.divisor = s->divisor.ptr + start;
+    P.bounce_pd = s->bounce_pd.ptr + start;
+    P.path_length = s->path_length.ptr + start;
+    P.nee = reinterpret_cast<float4 *>(s->nee.ptr) + start;
+    P.nee_stride = s->ws_slots;
+    P.nee_mask = s->nee_mask.ptr + start;
+    P.est = s->est.ptr + start;
+    P.cand = s->cand.ptr + static_cast<size_t>(start) * PT_MAX_CANDIDATES;
+    P.hit = s->hit.ptr + start;
+    P.vis = s->vis.ptr + static_cast<size_t>(start) * PT_MAX_NEE;
     return P;
 }
 
-PtQueue make_queue(pt_scene *s) {
+PtQueue make_queue(pt_scene *s, uint32_t group = 0) {
     PtQueue q{};
-    q.ray_o = reinterpret_cast<float4 *>(s->q_ray_o.ptr);
-    q.ray_d = reinterpret_cast<float4 *>(s->q_ray_d.ptr);
-    q.count = s->q_header.ptr;
-    q.head = s->q_header.ptr + PT_SHARDS * PT_QSTRIDE;
+    const size_t rays = static_cast<size_t>(s->shard_capacity) * PT_SHARDS;
+    q.ray_o = reinterpret_cast<float4 *>(s->q_ray_o.ptr) + group * rays;
+    q.ray_d = reinterpret_cast<float4 *>(s->q_ray_d.ptr) + group * rays;
+    q.count = s->q_header.ptr + static_cast<size_t>(group) * 2 * PT_SHARDS * PT_QSTRIDE;
+    q.head = q.count + PT_SHARDS * PT_QSTRIDE;
     q.shard_capacity = s->shard_capacity;
     return q;
 }
 
+PtCarry make_carry(pt_scene *s, uint32_t group = 0) {
+    PtCarry c{};
+    const size_t base = static_cast<size_t>(group) * 2 * s->carry_cap;
+    c.ray_o = reinterpret_cast<float4 *>(s->carry_o.ptr) + base;
+    c.ray_d = reinterpret_cast<float4 *>(s->carry_d.ptr) + base;
+    c.state = s->carry_state.ptr + base;
+    c.sp = s->carry_sp.ptr + base;
+    c.depth = std::max<uint32_t>(s->tree.depth, 1U);
+    c.stack = s->carry_stack.ptr + base * c.depth;
+    c.count = s->carry_header.ptr + static_cast<size_t>(group) * 4 * PT_QSTRIDE;
+    c.head = c.count + 2 * PT_QSTRIDE;
+    c.cap = s->carry_cap;
+    return c;
+}
+
 // workspace for n stream slots and a queue of `queue_rays_per_slot` rays per slot
-int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot) {
-    const uint32_t blocks = (n + 255) / 256;
+int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot, uint32_t groups = 1) {
+    // each group holds ceil(n / groups) slots (rounded up to whole 2048-slot units, see group_ranges)
+    const uint32_t per_group = ((n + groups - 1) / groups + 2047U) / 2048U * 2048U;
+    const uint32_t blocks = (per_group + 255) / 256;
     const uint32_t blocks_per_shard = (blocks + PT_SHARDS - 1) / PT_SHARDS;
     const uint32_t cap = std::max<uint32_t>(blocks_per_shard * 256U * rays_per_slot, 256U);
     PT_HIP(s->rect.ensure(n));
@@ -243,14 +279,45 @@ int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot) {
     PT_HIP(s->est.ensure(n));
     PT_HIP(s->cand.ensure(static_cast<size_t>(n) * PT_MAX_CANDIDATES));
     PT_HIP(s->hit.ensure(n));
-    PT_HIP(s->q_ray_o.ensure(static_cast<size_t>(cap) * PT_SHARDS));
-    PT_HIP(s->q_ray_d.ensure(static_cast<size_t>(cap) * PT_SHARDS));
-    PT_HIP(s->q_header.ensure(2 * PT_SHARDS * PT_QSTRIDE));
-    PT_HIP(s->counters.ensure(1));
-    s->shard_capacity = static_cast<uint32_t>(s->q_ray_o.count / PT_SHARDS);
-    s->ws_slots = n;
+    // `nee` is addressed as [plane][slot] with the allocation's slot count as stride: keep the stride in step with it
+    s->ws_slots = static_cast<uint32_t>(std::min<size_t>(s->nee.count / PT_MAX_NEE, 0xffffffffu));
+    const size_t want_rays = static_cast<size_t>(cap) * PT_SHARDS * groups;
+    if(s->q_ray_o.count < want_rays || s->ws_groups != groups || s->shard_capacity < cap) {
+        PT_HIP(s->q_ray_o.ensure(want_rays));
+        PT_HIP(s->q_ray_d.ensure(want_rays));
+        s->shard_capacity = cap;
+        s->ws_groups = groups;
+    }
+    PT_HIP(s->q_header.ensure(static_cast<size_t>(PT_MAX_GROUPS) * 2 * PT_SHARDS * PT_QSTRIDE));
+    PT_HIP(s->counters.ensure(PT_MAX_GROUPS));
+    PT_HIP(s->spill.ensure(static_cast<size_t>(s->trace_cfg.grid) * 256 * s->trace_cfg.spill_depth * groups));
+    {
+        // room for a quarter of a group's rays to be suspended at once (a full pool only means walks are not suspended)
+        const uint32_t want_cap = std::max<uint32_t>(4096U, per_group / 4U * rays_per_slot);
+        if(s->carry_cap < want_cap || s->carry_o.count < static_cast<size_t>(want_cap) * 2 * groups) {
+            s->carry_cap = std::max(s->carry_cap, want_cap);
+            const size_t total = static_cast<size_t>(s->carry_cap) * 2 * PT_MAX_GROUPS;
+            PT_HIP(s->carry_o.ensure(total));
+            PT_HIP(s->carry_d.ensure(total));
+            PT_HIP(s->carry_state.ensure(total));
+            PT_HIP(s->carry_sp.ensure(total));
+            PT_HIP(s->carry_stack.ensure(total * std::max<uint32_t>(s->tree.depth, 1U)));
+        }
+        PT_HIP(s->carry_header.ensure(static_cast<size_t>(PT_MAX_GROUPS) * 4 * PT_QSTRIDE));
+    }
+    s->trace_cfg.spill = s->spill.ptr;
+    if(env_int("PT_WALK_HIST", 0) != 0 && s->walk_hist.ptr == nullptr) {
+        PT_HIP(s->walk_hist.ensure(64));
+        PT_HIP(hipMemset(s->walk_hist.ptr, 0, 64 * sizeof(uint32_t)));
+        s->trace_cfg.walk_hist = s->walk_hist.ptr;
+    }
     if(s->host_counters == nullptr) {
-        PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->host_counters), sizeof(PtDevCounters), hipHostMallocDefault));
+        PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->host_counters), sizeof(PtDevCounters) * PT_MAX_GROUPS, hipHostMallocDefault));
+    }
+    for(uint32_t g = 0; g < groups; g++) {
+        if(s->group_stream[g] == nullptr) {
+            PT_HIP(hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking));
+        }
     }
     return PT_OK;
 }
@@ -271,8 +338,7 @@ int setup_trace(pt_scene *s) {
     const int limit = env_int("PT_TRACE_BLOCKS_PER_CU", 0);
     cfg.grid = s->cu_count * ((limit > 0 && limit < per_cu) ? limit : per_cu);
     cfg.spill_depth = s->tree.depth > static_cast<uint32_t>(stack_lds) ? s->tree.depth - static_cast<uint32_t>(stack_lds) : 1U;
-    PT_HIP(s->spill.ensure(static_cast<size_t>(cfg.grid) * 256 * cfg.spill_depth));
-    cfg.spill = s->spill.ptr;
+    cfg.spill = nullptr; // allocated with the workspace (one area per group)
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 20), 1), 64);
     cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 1), 1), 64);
     if(env_int("PT_DEBUG", 0) != 0) {
@@ -344,17 +410,59 @@ int check_render_args(pt_scene *scene, const pt_camera_params *camera, const pt_
 }
 
 // The wavefront loop over an initialised set of `n` stream slots.
-int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, uint32_t n, float4 *d_image, pt_stats *stats) {
-    PtPaths P = make_paths(s, n);
-    PtQueue q = make_queue(s);
-    hipStream_t st = s->stream;
-    PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters), st));
-    // no more workgroups than the rays one iteration can produce
-    PtTraceConfig trace_cfg = s->trace_cfg;
-    {
-        const uint64_t max_rays = static_cast<uint64_t>(n) * (1U + s->dev.n_lights + s->dev.n_object_samples);
-        const uint64_t blocks = (max_rays + 255) / 256;
-        trace_cfg.grid = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(trace_cfg.grid), blocks)));
+//
+// The slots are cut into up to PT_MAX_GROUPS contiguous groups, each with its own ray queue, counters and HIP stream.  A
+// group's iteration is shade -> trace on its stream; the groups are independent (a ray's destination is a slot of its own
+// group), so the drain phase of one group's persistent traversal kernel -- a few long walks through the glass mesh --
+// overlaps with the other groups' work instead of idling the chip.
+int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, uint32_t n, uint32_t groups, float4 *d_image, pt_stats *stats) {
+    const uint32_t rays_per_slot = 1U + s->dev.n_lights + s->dev.n_object_samples;
+    struct Group {
+        uint32_t start, count;
+        PtPaths P;
+        PtQueue q;
+        PtCarry carry;
+        PtTraceConfig cfg;
+        hipStream_t st;
+        bool done;
+    };
+    std::vector<Group> G(groups);
+    const int max_steps_env = env_int("PT_MAX_STEPS", 256);
+    const int max_steps = max_steps_env > 0 ? max_steps_env : 0x7fffffff;
+    const uint32_t per_group = ((n + groups - 1) / groups + 2047U) / 2048U * 2048U;
+    uint32_t n_groups = 0;
+    for(uint32_t g = 0; g < groups; g++) {
+        const uint32_t begin = std::min<uint64_t>(static_cast<uint64_t>(g) * per_group, n);
+        const uint32_t end = std::min<uint64_t>(static_cast<uint64_t>(g + 1) * per_group, n);
+        if(end <= begin) {
+            break;
+        }
+        Group &gr = G[n_groups];
+        gr.start = begin;
+        gr.count = end - begin;
+        gr.P = make_paths(s, gr.count, begin);
+        gr.q = make_queue(s, n_groups);
+        gr.carry = make_carry(s, n_groups);
+        gr.cfg = s->trace_cfg;
+        gr.cfg.max_steps = max_steps;
+        // no more workgroups than the rays one iteration can produce
+        const uint64_t blocks = (static_cast<uint64_t>(gr.count) * rays_per_slot + 255) / 256;
+        gr.cfg.grid = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(gr.cfg.grid), blocks)));
+        gr.cfg.spill = s->spill.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 256 * s->trace_cfg.spill_depth;
+        gr.st = s->group_stream[n_groups];
+        gr.done = false;
+        n_groups++;
+    }
+    G.resize(n_groups);
+
+    // order the groups' streams after the initialisation that ran on the main stream
+    hipEvent_t ev_init;
+    PT_HIP(hipEventCreateWithFlags(&ev_init, hipEventDisableTiming));
+    PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters) * PT_MAX_GROUPS, s->stream));
+    PT_HIP(hipMemsetAsync(s->carry_header.ptr, 0, static_cast<size_t>(PT_MAX_GROUPS) * 4 * PT_QSTRIDE * sizeof(uint32_t), s->stream));
+    PT_HIP(hipEventRecord(ev_init, s->stream));
+    for(Group &gr : G) {
+        PT_HIP(hipStreamWaitEvent(gr.st, ev_init, 0));
     }
 
     const bool timing = stats != nullptr;
@@ -368,9 +476,10 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         }
         PT_HIP(hipEventCreate(&ev_begin));
         PT_HIP(hipEventCreate(&ev_end));
-        PT_HIP(hipEventRecord(ev_begin, st));
+        PT_HIP(hipEventRecord(ev_begin, s->stream));
     }
     double trace_ms = 0.0, shade_ms = 0.0;
+    uint64_t launches = 0;
     auto drain_events = [&](int used) -> int {
         for(int i = 0; i < used; i++) {
             float a = 0.0F, b = 0.0F;
@@ -388,55 +497,91 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     int pending = 0;
     for(;;) {
         for(int k = 0; k < check_every; k++) {
-            PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, 2 * PT_SHARDS * PT_QSTRIDE * sizeof(uint32_t), st));
-            if(timing) {
-                PT_HIP(hipEventRecord(ev[4 * pending + 0], st));
-            }
-            pt_launch_shade(st, s->dev, cam, opt, P, q, d_image, s->counters.ptr);
-            if(timing) {
-                PT_HIP(hipEventRecord(ev[4 * pending + 1], st));
-                PT_HIP(hipEventRecord(ev[4 * pending + 2], st));
-            }
-            pt_launch_trace(st, s->dev, q, P, trace_cfg, s->counters.ptr);
-            if(timing) {
-                PT_HIP(hipEventRecord(ev[4 * pending + 3], st));
-                if(++pending == kEventPairs) {
-                    int rc = drain_events(pending);
-                    if(rc != PT_OK) {
-                        return rc;
+            for(size_t g = 0; g < G.size(); g++) {
+                Group &gr = G[g];
+                if(gr.done) {
+                    continue;
+                }
+                PtDevCounters *cnt = s->counters.ptr + g;
+                PT_HIP(hipMemsetAsync(gr.q.count, 0, 2 * PT_SHARDS * PT_QSTRIDE * sizeof(uint32_t), gr.st));
+                if(timing) {
+                    PT_HIP(hipEventRecord(ev[4 * pending + 0], gr.st));
+                }
+                const int parity = static_cast<int>(iterations & 1U);
+                gr.cfg.parity = parity;
+                pt_launch_shade(gr.st, s->dev, cam, opt, gr.P, gr.q, gr.carry, parity, d_image, cnt);
+                if(timing) {
+                    PT_HIP(hipEventRecord(ev[4 * pending + 1], gr.st));
+                    PT_HIP(hipEventRecord(ev[4 * pending + 2], gr.st));
+                }
+                pt_launch_trace(gr.st, s->dev, gr.q, gr.carry, gr.P, gr.cfg, cnt);
+                launches++;
+                if(timing) {
+                    PT_HIP(hipEventRecord(ev[4 * pending + 3], gr.st));
+                    if(++pending == kEventPairs) {
+                        int rc = drain_events(pending);
+                        if(rc != PT_OK) {
+                            return rc;
+                        }
+                        pending = 0;
                     }
-                    pending = 0;
                 }
             }
             iterations++;
         }
-        PT_HIP(hipMemcpyAsync(s->host_counters, s->counters.ptr, sizeof(PtDevCounters), hipMemcpyDeviceToHost, st));
-        PT_HIP(hipStreamSynchronize(st));
+        bool all_done = true;
+        for(size_t g = 0; g < G.size(); g++) {
+            if(!G[g].done) {
+                PT_HIP(hipMemcpyAsync(s->host_counters + g, s->counters.ptr + g, sizeof(PtDevCounters), hipMemcpyDeviceToHost, G[g].st));
+            }
+        }
+        for(size_t g = 0; g < G.size(); g++) {
+            if(!G[g].done) {
+                PT_HIP(hipStreamSynchronize(G[g].st));
+                G[g].done = s->host_counters[g].streams_done >= G[g].count;
+            }
+            all_done = all_done && G[g].done;
+        }
         PT_HIP(hipGetLastError());
-        if(s->host_counters->streams_done >= n) {
+        if(all_done) {
             break;
         }
         if(iterations > (1ULL << 40)) {
             return fail(PT_ERR_HIP, "wavefront loop did not terminate");
         }
     }
+    // the main stream continues after every group
+    for(Group &gr : G) {
+        PT_HIP(hipEventRecord(ev_init, gr.st));
+        PT_HIP(hipStreamWaitEvent(s->stream, ev_init, 0));
+    }
+    (void)hipEventDestroy(ev_init);
     if(timing) {
         int rc = drain_events(pending);
         if(rc != PT_OK) {
             return rc;
         }
-        PT_HIP(hipEventRecord(ev_end, st));
+        PT_HIP(hipEventRecord(ev_end, s->stream));
         PT_HIP(hipEventSynchronize(ev_end));
         float total = 0.0F;
         PT_HIP(hipEventElapsedTime(&total, ev_begin, ev_end));
-        const PtDevCounters &c = *s->host_counters;
+        PtDevCounters c{};
+        for(size_t g = 0; g < G.size(); g++) {
+            const PtDevCounters &h = s->host_counters[g];
+            c.samples += h.samples;
+            c.rays += h.rays;
+            c.shadow_rays += h.shadow_rays;
+            c.node_visits += h.node_visits;
+            c.leaf_tests += h.leaf_tests;
+            c.vertices += h.vertices;
+        }
         stats->samples = c.samples;
         stats->rays_traced = c.rays;
         stats->shadow_rays_traced = c.shadow_rays;
         stats->node_visits = c.node_visits;
         stats->leaf_tests = c.leaf_tests;
         stats->vertices = c.vertices;
-        stats->iterations = iterations;
+        stats->iterations = launches;
         stats->trace_ms = trace_ms;
         stats->shade_ms = shade_ms;
         stats->total_ms = total;
@@ -447,6 +592,13 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         (void)hipEventDestroy(ev_end);
     }
     return PT_OK;
+}
+
+uint32_t choose_groups(uint32_t n) {
+    const int want = std::min(std::max(env_int("PT_GROUPS", 1), 1), PT_MAX_GROUPS);
+    // a group should still fill the chip's lanes on its own now and then: at least 128 K streams per group
+    const uint32_t by_size = std::max<uint32_t>(1U, n / 131072U);
+    return std::min<uint32_t>(static_cast<uint32_t>(want), by_size);
 }
 
 } // namespace
@@ -760,6 +912,16 @@ void pt_scene_destroy(pt_scene *scene) {
     if(scene->stream != nullptr) {
         (void)hipStreamSynchronize(scene->stream);
     }
+    if(scene->walk_hist.ptr != nullptr) {
+        uint32_t h[64];
+        if(hipMemcpy(h, scene->walk_hist.ptr, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            std::fprintf(stderr, "[pt] inner-node steps per walk (bucket b: 2^(b-1) <= steps < 2^b):");
+            for(int b = 0; b < 16; b++) {
+                std::fprintf(stderr, " %u", h[b]);
+            }
+            std::fprintf(stderr, "\n");
+        }
+    }
     delete scene;
 }
 
@@ -809,7 +971,7 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
     }
     PT_HIP(hipSetDevice(s->device));
     const uint32_t n32 = static_cast<uint32_t>(n);
-    int rc = ensure_workspace(s, std::max(n32, s->ws_slots), 1U + s->dev.n_lights + s->dev.n_object_samples);
+    int rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples);
     if(rc != PT_OK) {
         return rc;
     }
@@ -825,8 +987,14 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
     PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters), st));
     pt_launch_batch_rays(st, s->batch_rays.ptr, n32, q);
     PtTraceConfig trace_cfg = s->trace_cfg;
+    trace_cfg.spill = s->spill.ptr;
     trace_cfg.grid = static_cast<int>(std::max<uint32_t>(1U, std::min<uint32_t>(static_cast<uint32_t>(trace_cfg.grid), (n32 + 255U) / 256U)));
-    pt_launch_trace(st, s->dev, q, P, trace_cfg, s->counters.ptr);
+    trace_cfg.max_steps = 0x7fffffff;
+    trace_cfg.parity = 0;
+    PT_HIP(hipMemsetAsync(s->carry_header.ptr, 0, 4 * PT_QSTRIDE * sizeof(uint32_t), st));
+    PtCarry carry = make_carry(s, 0);
+    carry.cap = 0;
+    pt_launch_trace(st, s->dev, q, carry, P, trace_cfg, s->counters.ptr);
     std::vector<uint2> hits(n);
     PT_HIP(hipMemcpyAsync(hits.data(), s->hit.ptr, n * sizeof(uint2), hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
@@ -884,7 +1052,8 @@ int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_opti
     }
     PT_HIP(hipSetDevice(s->device));
     const uint32_t n32 = static_cast<uint32_t>(n);
-    rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples);
+    const uint32_t groups = choose_groups(n32);
+    rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples, groups);
     if(rc != PT_OK) {
         return rc;
     }
@@ -896,7 +1065,7 @@ int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_opti
     PT_HIP(hipMemcpyAsync(s->rect.ptr, rects.data(), n * sizeof(int4), hipMemcpyHostToDevice, st));
     PT_HIP(hipMemcpyAsync(s->rng.ptr, states.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     pt_launch_init_streams(st, make_paths(s, n32));
-    rc = run_wavefront(s, cam, opt, n32, reinterpret_cast<float4 *>(s->image.ptr), stats);
+    rc = run_wavefront(s, cam, opt, n32, groups, reinterpret_cast<float4 *>(s->image.ptr), stats);
     if(rc != PT_OK) {
         return rc;
     }
@@ -932,7 +1101,8 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
         return fail(PT_ERR_INVALID, "too many pixels in one call");
     }
     const uint32_t n32 = static_cast<uint32_t>(total);
-    rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples);
+    const uint32_t groups = choose_groups(n32);
+    rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples, groups);
     if(rc != PT_OK) {
         return rc;
     }
@@ -943,7 +1113,7 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
     PT_HIP(hipMemcpyAsync(s->tile_offset.ptr, offsets.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     pt_launch_init_tiles(st, make_paths(s, n32), s->tiles.ptr, s->tile_offset.ptr, static_cast<uint32_t>(n_tiles), base_seed);
     PT_HIP(hipStreamSynchronize(st)); // rects/offsets are stack-owned host vectors
-    return run_wavefront(s, cam, opt, n32, d_image, stats);
+    return run_wavefront(s, cam, opt, n32, groups, d_image, stats);
 }
 
 int pt_render_tiles(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles, uint64_t base_seed,

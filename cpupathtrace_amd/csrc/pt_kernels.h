@@ -24,7 +24,8 @@ struct PtPaths {
     double *divisor;       // sample_divisor (worker.cpp:39)
     double *bounce_pd;     // sample_bounce_pd (worker.cpp:40)
     int32_t *path_length;  // worker.cpp:43
-    float4 *nee;           // [PT_MAX_NEE][n] weighed_spectrum of the pending shadow rays (worker.cpp:97)
+    float4 *nee;           // [PT_MAX_NEE][nee_stride] weighed_spectrum of the pending shadow rays (worker.cpp:97)
+    uint32_t nee_stride;   // slots between two light-sample planes of `nee` (the workspace size; >= n for a group view)
     uint32_t *nee_mask;    // bit j: light sample j of the last vertex contributes if its shadow ray is unoccluded
     PtEstimator *est;      // per-pixel estimator (worker.cpp:172-192)
     PtCandidate *cand;     // [n][PT_MAX_CANDIDATES]
@@ -38,6 +39,7 @@ struct PtPaths {
 #define PT_F_HAS_EXT 4u   /* an extension (camera/bounce) ray was traced for it */
 #define PT_F_COLLECTED 8u /* sample_collected (worker.cpp:37) */
 #define PT_F_PIXEL 16u    /* the estimator of the current pixel is initialised */
+#define PT_F_OVERLAP 32u  /* the next sample's camera ray is already in flight while the previous sample waits for its last shadow rays */
 
 // Ray queue: PT_SHARDS append-only segments of `shard_capacity` rays each.
 struct PtQueue {
@@ -46,6 +48,21 @@ struct PtQueue {
     uint32_t *count; // [PT_SHARDS * PT_QSTRIDE] rays appended to shard s at count[s * PT_QSTRIDE]
     uint32_t *head;  // [PT_SHARDS * PT_QSTRIDE] rays dequeued from shard s at head[s * PT_QSTRIDE]
     uint32_t shard_capacity;
+};
+
+// Walks suspended by one traversal launch and resumed by the next one (two pools used alternately).  A launch gives every walk
+// a budget of inner-node steps; the few walks that need thousands of steps (rays grazing the mesh) would otherwise keep the
+// whole launch -- and with it every stream of the wavefront -- waiting for them.
+struct PtCarry {
+    float4 *ray_o;   // [2][cap] origin, shadow threshold
+    float4 *ray_d;   // [2][cap] direction, destination
+    uint4 *state;    // [2][cap] bits best_t, best_ref, bits t_max, current node
+    uint32_t *sp;    // [2][cap] saved stack entries
+    uint2 *stack;    // [2][cap][depth]
+    uint32_t *count; // [2 * PT_QSTRIDE] walks stored in pool i at count[i * PT_QSTRIDE] (may exceed cap: the excess was not stored)
+    uint32_t *head;  // [2 * PT_QSTRIDE] walks taken out of pool i
+    uint32_t cap;
+    uint32_t depth;
 };
 
 #define PT_DEST_SHADOW 0x80000000u
@@ -60,13 +77,17 @@ struct PtTraceConfig {
     int refill_idle;      // a wavefront refills from the queue once this many of its 64 lanes are idle
     int leaf_min;         // leaf tests run once this many lanes stand on a leaf (or no lane has an inner node left)
     int lds_mode;         // 0: no LDS staging, 1: top of the tree in LDS, 2: whole tree + triangles in LDS
+    uint32_t *walk_hist;  // optional [33] histogram of inner-node steps per finished walk (PT_WALK_HIST=1), else null
+    int max_steps;        // inner-node steps a walk may take in one launch before it is suspended
+    int parity;           // this launch resumes pool `parity` and suspends into pool `parity ^ 1`
 };
 
 void pt_launch_init_tiles(hipStream_t stream, PtPaths paths, const int4 *tiles, const uint32_t *tile_offset, uint32_t n_tiles, uint64_t base_seed);
 void pt_launch_init_streams(hipStream_t stream, PtPaths paths);
 void pt_launch_shade(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtPaths paths, PtQueue queue,
-                     float4 *image, PtDevCounters *counters);
-void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters);
+                     PtCarry carry, int parity, float4 *image, PtDevCounters *counters);
+void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtCarry carry, PtPaths paths, const PtTraceConfig &cfg,
+                     PtDevCounters *counters);
 void pt_launch_batch_rays(hipStream_t stream, const float *rays6, uint32_t n, PtQueue queue);
 int pt_trace_blocks_per_cu(int stack_lds, int lds_mode, size_t lds_bytes);
 

@@ -9,6 +9,9 @@
 //              (Scene::sampleLights, scene.cpp:222-289) with one shadow ray per light sample, BSDF sample (:117-131).
 //              A finished sample goes through the estimator and the stream immediately starts its next sample (or pixel).
 //   trace(i):  all rays appended by shade(i).
+// A path that ends at a vertex (roulette) still has that vertex's shadow rays to wait for; where the estimator provably cannot
+// stop at this sample, the NEXT sample's camera ray is drawn and traced in the same iteration (PT_F_OVERLAP) -- the draws keep
+// their order (all draws of the ending sample are made), and one iteration per sample is saved.
 // The random draws of one stream are consumed strictly in the reference's order because a stream has at most one path in
 // flight and every draw of a vertex (roulette, lights, BSDF) is made by the single invocation that shades the vertex.
 //
@@ -289,18 +292,35 @@ PT_D bool sample_emissive(const PtDevScene &sc, V3 pos, uint64_t &rng, V3 &light
 
 // ---- the kernel -------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamera cam, PtDevOptions opt, PtPaths P, PtQueue q, float4 *__restrict__ image,
-                                                       PtDevCounters *counters) {
+__global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamera cam, PtDevOptions opt, PtPaths P, PtQueue q, PtCarry carry, int parity,
+                                                       float4 *__restrict__ image, PtDevCounters *counters) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const uint32_t shard = blockIdx.x % PT_SHARDS;
     const uint32_t n_light_samples = sc.n_lights + sc.n_object_samples;
 
+    if(p == 0) {
+        // the traversal launch that follows resumes pool `parity` and suspends into pool `parity ^ 1`
+        carry.count[(parity ^ 1) * PT_QSTRIDE] = 0;
+        carry.head[parity * PT_QSTRIDE] = 0;
+    }
+
     uint32_t flags = PT_F_DONE;
     if(p < P.n) {
         flags = P.flags[p];
     }
-    const bool alive = !(flags & PT_F_DONE);
+    bool alive = !(flags & PT_F_DONE);
+    if(alive && (flags & PT_F_IN_FLIGHT)) {
+        // a stream whose rays are still walking (suspended by the last traversal launch) sits this iteration out
+        bool ready = !(flags & PT_F_HAS_EXT) || P.hit[p].y != PT_REF_PENDING;
+        uint32_t mask = P.nee_mask[p];
+        for(uint32_t j = 0; mask != 0; j++, mask >>= 1) {
+            if((mask & 1u) && P.vis[(size_t)p * PT_MAX_NEE + j] == PT_VIS_PENDING) {
+                ready = false;
+            }
+        }
+        alive = ready;
+    }
 
     // ---- phase A: consume the results of the previous iteration ------------------------------------------------------
     uint64_t rng = 0;
@@ -323,8 +343,20 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
             uint32_t mask = P.nee_mask[p];
             for(uint32_t j = 0; mask != 0; j++, mask >>= 1) {
                 if((mask & 1u) && P.vis[(size_t)p * PT_MAX_NEE + j] != 0u) {
-                    out = out + c4(P.nee[(size_t)j * P.n + p]);
+                    out = out + c4(P.nee[(size_t)j * P.nee_stride + p]);
                 }
+            }
+            if(flags & PT_F_OVERLAP) {
+                // the previous sample is complete now (worker.cpp:141-145, 196-237); it was collected (it had a vertex), it is
+                // not the pixel's last sample and the estimator cannot accept at it (see safe_overlap below)
+                PtEstimator e = P.est[p];
+                out.a = 1.0f;
+                (void)estimator_add(e, P.cand + (size_t)p * PT_MAX_CANDIDATES, opt, out);
+                e.pixel_sample++;
+                n_samples++;
+                P.est[p] = e;
+                flags &= ~(PT_F_OVERLAP | PT_F_COLLECTED);
+                out = c4(0, 0, 0, 0);
             }
             bool finished = true;
             if(flags & PT_F_HAS_EXT) {
@@ -382,6 +414,15 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
     Ray ext;
     ext.o = v3(0, 0, 0);
     ext.d = v3(0, 0, 1);
+    // camera ray through pixel `cur` of the stream's rectangle (worker.cpp:168-170, camera.cpp:78-113)
+    auto shoot_camera = [&](const int4 rc, int32_t cur) {
+        const int32_t px = rc.x + cur % rc.z, py = rc.y + cur / rc.z;
+        const float one_half = 1.0f / 2.0f;
+        const float x_camera = 2 * (((float)px + one_half) / (float)opt.image_width - one_half);
+        float y_camera = 2 * (((float)py + one_half) / (float)opt.image_height - one_half);
+        y_camera = -y_camera;
+        return camera_shoot(cam, x_camera, y_camera, opt.pixel_width, opt.pixel_height, rng);
+    };
     if(start_sample) {
         const int4 rc = P.rect[p];
         int32_t cur = P.cursor[p];
@@ -410,13 +451,7 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
             atomicAdd(&counters->streams_done, 1ULL);
         }
         else {
-            // worker.cpp:168-170
-            const int32_t px = rc.x + cur % rc.z, py = rc.y + cur / rc.z;
-            const float one_half = 1.0f / 2.0f;
-            const float x_camera = 2 * (((float)px + one_half) / (float)opt.image_width - one_half);
-            float y_camera = 2 * (((float)py + one_half) / (float)opt.image_height - one_half);
-            y_camera = -y_camera;
-            ext = camera_shoot(cam, x_camera, y_camera, opt.pixel_width, opt.pixel_height, rng);
+            ext = shoot_camera(rc, cur);
             emit_ext = true;
             out = c4(0, 0, 0, 0);
             spectrum = c4(1, 1, 1, 1);
@@ -435,6 +470,7 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
     bool do_bounce = false;
     float bounce_probability = 1.0f;
     bool want_nee = false;
+    bool safe_overlap = false;
     if(shade_vertex) {
         path_length++;
         flags |= PT_F_COLLECTED;
@@ -451,7 +487,18 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
         // BSDF::getSpectrum(..., synthetic = true) returns p = 0 for glass and mirror: their light samples never
         // contribute (worker.cpp:92), so no shadow ray is needed -- the light-sampling draws are still consumed below.
         want_nee = mat.bsdf == 0 && n_light_samples > 0;
-        emit_ext = do_bounce; // may still be cancelled by the 1E-20 guards (worker.cpp:112,134)
+        // Can the next sample start before this one is handed to the estimator?  Only if another sample of the same pixel
+        // certainly follows: this is not the last one (worker.cpp:193) and the convergence test cannot run at it -- the test
+        // runs only when this sample closes a statistics batch with at least max(min_sample_count, 2) samples collected
+        // (worker.cpp:239).
+        {
+            const PtEstimator *e = P.est + p;
+            const bool closes_batch = e->stats_sample_index + 1 == opt.stats_sample_count;
+            const int min_needed = opt.min_sample_count > 2 ? opt.min_sample_count : 2;
+            safe_overlap = e->pixel_sample + 1 < opt.max_sample_count && !(closes_batch && e->collected_sample_count + 1 >= min_needed);
+        }
+        // an extension ray: the bounce (may still be cancelled by the 1E-20 guards, worker.cpp:112,134) or the next sample's camera ray
+        emit_ext = do_bounce || safe_overlap;
     }
 
     // ---- reserve queue space: one atomic per wave -----------------------------------------------------------------------------
@@ -501,7 +548,7 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
                     const C4 weighed = combined / (float)(divisor * bounce_pd * lpd * shadow_ray_pd);
                     // adding +-0 never changes out_spectrum (which is never -0), so such a sample needs no ray
                     if(!(weighed.r == 0.0f && weighed.g == 0.0f && weighed.b == 0.0f)) {
-                        P.nee[(size_t)j * P.n + p] = f4(weighed);
+                        P.nee[(size_t)j * P.nee_stride + p] = f4(weighed);
                         nee_out_mask |= 1u << j;
                         const float threshold = len(to_light) - epsilon;
                         if(threshold <= 0.0f) {
@@ -510,6 +557,7 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
                         }
                         else {
                             need_ray = true;
+                            P.vis[(size_t)p * PT_MAX_NEE + j] = PT_VIS_PENDING;
                             const V3 so = pos + light_dir * epsilon;
                             q.ray_o[nee_slot + j] = make_float4(so.x, so.y, so.z, threshold);
                             q.ray_d[nee_slot + j] =
@@ -552,7 +600,18 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
                 }
             }
         }
-        if(emit_ext && cancel_ext) {
+        const bool path_ends = !do_bounce || cancel_ext;
+        if(path_ends && safe_overlap) {
+            // start the next sample of this pixel now; this sample is finished by the next invocation (PT_F_OVERLAP)
+            ext = shoot_camera(P.rect[p], P.cursor[p]);
+            spectrum = c4(1, 1, 1, 1);
+            contribution_unweighted = 1.0f;
+            divisor = 1.0;
+            bounce_pd = 1.0;
+            path_length = 0;
+            flags |= PT_F_OVERLAP;
+        }
+        else if(path_ends && emit_ext) {
             q.ray_d[slot0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PT_DEST_NULL));
             emit_ext = false;
         }
@@ -568,6 +627,7 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
     if(emit_ext) {
         q.ray_o[slot0] = make_float4(ext.o.x, ext.o.y, ext.o.z, 0.0f);
         q.ray_d[slot0] = make_float4(ext.d.x, ext.d.y, ext.d.z, __uint_as_float(p));
+        P.hit[p] = make_uint2(0u, PT_REF_PENDING);
     }
     if(alive) {
         P.flags[p] = flags;
@@ -656,9 +716,9 @@ void pt_launch_init_streams(hipStream_t stream, PtPaths paths) {
 }
 
 void pt_launch_shade(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtPaths paths, PtQueue queue,
-                     float4 *image, PtDevCounters *counters) {
+                     PtCarry carry, int parity, float4 *image, PtDevCounters *counters) {
     if(paths.n == 0) {
         return;
     }
-    hipLaunchKernelGGL(pt_shade_kernel, dim3((paths.n + 255) / 256), dim3(256), 0, stream, scene, camera, options, paths, queue, image, counters);
+    hipLaunchKernelGGL(pt_shade_kernel, dim3((paths.n + 255) / 256), dim3(256), 0, stream, scene, camera, options, paths, queue, carry, parity, image, counters);
 }

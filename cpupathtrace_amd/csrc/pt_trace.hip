@@ -73,9 +73,10 @@ PT_D float slab_walk(V3 lo, V3 hi, V3 o, V3 inv) {
 //           1 = records with index < n_lds_* come from LDS, the rest from HBM (breadth-first top of the tree),
 //           2 = the whole tree and all triangles are in LDS (small scenes).
 template<int STACK_LDS, int LDS_MODE, bool COUNT>
-__global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, uint2 *__restrict__ hit, uint32_t *__restrict__ vis,
+__global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, PtCarry carry, int parity, int max_steps, uint2 *__restrict__ hit,
+                                                       uint32_t *__restrict__ vis,
                                                        uint2 *__restrict__ spill, uint32_t spill_depth, int refill_idle, int leaf_min,
-                                                       PtDevCounters *counters) {
+                                                       PtDevCounters *counters, uint32_t *walk_hist) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     uint2 *lds_stack = reinterpret_cast<uint2 *>(lds_raw);
     float4 *lds_pairs = reinterpret_cast<float4 *>(lds_raw + (size_t)STACK_LDS * 256 * sizeof(uint2));
@@ -106,8 +107,14 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     uint32_t shard = blockIdx.x % PT_SHARDS;
     uint32_t shards_tried = 0;
     bool exhausted = false;
-    // rays reserved by this wavefront and not yet handed to a lane (wave-uniform)
+    // rays reserved by this wavefront and not yet handed to a lane (wave-uniform); suspended walks of the previous launch
+    // (pool `parity`) are reserved first, so the long walks start early
     uint32_t res_next = 0, res_end = 0;
+    bool res_is_carry = false;
+    const uint32_t carry_in = parity, carry_out = parity ^ 1;
+    const uint32_t carry_count_raw = carry.count[carry_in * PT_QSTRIDE];
+    const uint32_t carry_count = carry_count_raw < carry.cap ? carry_count_raw : carry.cap;
+    bool carry_done = carry_count == 0;
 
     // per-lane traversal state; cur == PT_REF_NONE on an active lane means "walk finished, result not yet written"
     bool active = false;
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     uint32_t cur = PT_REF_NONE;
     int sp = 0;
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0;
+    uint32_t walk_start = 0; // n_nodes when the current walk began (diagnostic histogram of walk lengths)
 
     for(;;) {
         // ---- 1. retire finished walks ----------------------------------------------------------------------------------
@@ -131,15 +139,35 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 hit[dest] = make_uint2(__float_as_uint(best_ref == PT_REF_NONE ? -1.0f : best_t), best_ref);
             }
             active = false;
+            if(COUNT && walk_hist != nullptr) {
+                const uint32_t steps = n_nodes - walk_start;
+                atomicAdd(&walk_hist[32 - __clz((int)steps)], 1u); // bucket b: 2^(b-1) <= steps < 2^b, bucket 0: no step
+            }
         }
 
         // ---- 2. refill idle lanes ----------------------------------------------------------------------------------------
         const unsigned long long idle_mask = __ballot(!active);
         const int n_idle = __popcll(idle_mask);
-        if(n_idle >= refill_idle && (res_next < res_end || !exhausted)) {
+        if(n_idle >= refill_idle && (res_next < res_end || !exhausted || !carry_done)) {
             if(res_next >= res_end) {
+                res_is_carry = false;
+                if(!carry_done) {
+                    uint32_t base = 0;
+                    if(lane == 0) {
+                        base = atomicAdd(&carry.head[carry_in * PT_QSTRIDE], (uint32_t)PT_QCHUNK);
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if(base < carry_count) {
+                        res_next = carry_in * carry.cap + base;
+                        res_end = res_next + (carry_count - base < PT_QCHUNK ? carry_count - base : (uint32_t)PT_QCHUNK);
+                        res_is_carry = true;
+                    }
+                    else {
+                        carry_done = true;
+                    }
+                }
                 // reserve the next PT_QCHUNK rays: own shard first, then the others
-                while(!exhausted) {
+                while(!res_is_carry && !exhausted) {
                     const uint32_t count = q.count[shard * PT_QSTRIDE];
                     // heads only grow: a (possibly stale) head at or past the end means the shard is drained, no atomic needed
                     if(__hip_atomic_load(&q.head[shard * PT_QSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < count) {
@@ -165,7 +193,37 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             res_next += avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
             if(!active) {
                 const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
-                if(rank < avail) {
+                if(rank < avail && res_is_carry) {
+                    // resume a suspended walk
+                    const uint32_t c = first + rank;
+                    const float4 ro = carry.ray_o[c];
+                    const float4 rd = carry.ray_d[c];
+                    const uint4 st = carry.state[c];
+                    o = v3(ro.x, ro.y, ro.z);
+                    d = v3(rd.x, rd.y, rd.z);
+                    thr = ro.w;
+                    dest = __float_as_uint(rd.w);
+                    inv = slab_inverse(d);
+                    best_t = __uint_as_float(st.x);
+                    best_ref = st.y;
+                    t_max = __uint_as_float(st.z);
+                    cur = st.w;
+                    sp = (int)carry.sp[c];
+                    const uint2 *saved = carry.stack + (size_t)c * carry.depth;
+                    for(int i = 0; i < sp; i++) {
+                        const uint2 e = saved[i];
+                        const u2v ev = {e.x, e.y};
+                        if(i < STACK_LDS) {
+                            stack_l[i * 256 + tid] = ev;
+                        }
+                        else {
+                            my_spill[i - STACK_LDS] = ev;
+                        }
+                    }
+                    active = true;
+                    walk_start = n_nodes;
+                }
+                else if(rank < avail) {
                     const float4 ro = q.ray_o[first + rank];
                     const float4 rd = q.ray_d[first + rank];
                     dest = __float_as_uint(rd.w);
@@ -183,6 +241,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                             n_rays++;
                             n_shadow += (dest & PT_DEST_SHADOW) ? 1 : 0;
                         }
+                        walk_start = n_nodes;
                         // Scene::getIntersection: root box first (scene.cpp:211-219)
                         cur = PT_REF_NONE;
                         if(sc.root_ref != PT_REF_NONE) {
@@ -196,7 +255,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             }
         }
         if(__ballot(active) == 0ULL) {
-            if(exhausted && res_next >= res_end) {
+            if(exhausted && carry_done && res_next >= res_end) {
                 break;
             }
             continue;
@@ -273,6 +332,39 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                             break;
                         }
                     }
+                }
+            }
+        }
+
+        // ---- 3b. suspend walks that used up this launch's step budget -------------------------------------------------------------
+        {
+            const bool over = active && cur != PT_REF_NONE && (n_nodes - walk_start) >= (uint32_t)max_steps;
+            const unsigned long long over_mask = __ballot(over);
+            if(over_mask != 0ULL) {
+                uint32_t base = 0;
+                if(lane == 0) {
+                    base = atomicAdd(&carry.count[carry_out * PT_QSTRIDE], (uint32_t)__popcll(over_mask));
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t slot = base + (uint32_t)__popcll(over_mask & ((1ULL << lane) - 1ULL));
+                if(over && slot < carry.cap) { // a full pool just means the walk keeps running in this launch
+                    const uint32_t c = carry_out * carry.cap + slot;
+                    carry.ray_o[c] = make_float4(o.x, o.y, o.z, thr);
+                    carry.ray_d[c] = make_float4(d.x, d.y, d.z, __uint_as_float(dest));
+                    carry.state[c] = make_uint4(__float_as_uint(best_t), best_ref, __float_as_uint(t_max), cur);
+                    carry.sp[c] = (uint32_t)sp;
+                    uint2 *saved = carry.stack + (size_t)c * carry.depth;
+                    for(int i = 0; i < sp; i++) {
+                        u2v e;
+                        if(i < STACK_LDS) {
+                            e = stack_l[i * 256 + tid];
+                        }
+                        else {
+                            e = my_spill[i - STACK_LDS];
+                        }
+                        saved[i] = make_uint2(e.x, e.y);
+                    }
+                    active = false;
                 }
             }
         }
@@ -384,22 +476,25 @@ __global__ void pt_batch_rays_kernel(const float *__restrict__ rays6, uint32_t n
 }
 
 template<int STACK_LDS, int LDS_MODE>
-void launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters) {
-    hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, LDS_MODE, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, paths.hit, paths.vis,
-                       cfg.spill, cfg.spill_depth, cfg.refill_idle, cfg.leaf_min, counters);
+void launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtCarry carry, PtPaths paths, const PtTraceConfig &cfg,
+                  PtDevCounters *counters) {
+    hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, LDS_MODE, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, carry, cfg.parity, cfg.max_steps, paths.hit,
+                       paths.vis,
+                       cfg.spill, cfg.spill_depth, cfg.refill_idle, cfg.leaf_min, counters, cfg.walk_hist);
 }
 
 template<int STACK_LDS>
-void launch_trace_mode(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters) {
+void launch_trace_mode(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtCarry carry, PtPaths paths, const PtTraceConfig &cfg,
+                       PtDevCounters *counters) {
     switch(cfg.lds_mode) {
         case 0:
-            launch_trace<STACK_LDS, 0>(stream, scene, queue, paths, cfg, counters);
+            launch_trace<STACK_LDS, 0>(stream, scene, queue, carry, paths, cfg, counters);
             break;
         case 2:
-            launch_trace<STACK_LDS, 2>(stream, scene, queue, paths, cfg, counters);
+            launch_trace<STACK_LDS, 2>(stream, scene, queue, carry, paths, cfg, counters);
             break;
         default:
-            launch_trace<STACK_LDS, 1>(stream, scene, queue, paths, cfg, counters);
+            launch_trace<STACK_LDS, 1>(stream, scene, queue, carry, paths, cfg, counters);
             break;
     }
 }
@@ -424,16 +519,17 @@ int occupancy_mode(int lds_mode, size_t lds_bytes) {
 
 } // namespace
 
-void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtPaths paths, const PtTraceConfig &cfg, PtDevCounters *counters) {
+void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtCarry carry, PtPaths paths, const PtTraceConfig &cfg,
+                     PtDevCounters *counters) {
     switch(cfg.stack_lds) {
         case 8:
-            launch_trace_mode<8>(stream, scene, queue, paths, cfg, counters);
+            launch_trace_mode<8>(stream, scene, queue, carry, paths, cfg, counters);
             break;
         case 24:
-            launch_trace_mode<24>(stream, scene, queue, paths, cfg, counters);
+            launch_trace_mode<24>(stream, scene, queue, carry, paths, cfg, counters);
             break;
         default:
-            launch_trace_mode<16>(stream, scene, queue, paths, cfg, counters);
+            launch_trace_mode<16>(stream, scene, queue, carry, paths, cfg, counters);
             break;
     }
 }

@@ -32,6 +32,8 @@
 #define PT_REF_SPHERE 0x40000000u
 #define PT_REF_INDEX 0x3fffffffu
 #define PT_REF_NONE 0xffffffffu /* also: a leaf holding the NullObject of an empty scene */
+#define PT_REF_PENDING 0xfffffffeu /* in a hit record: the extension ray has not finished its walk yet */
+#define PT_VIS_PENDING 2u          /* in a visibility word: the shadow ray has not finished its walk yet */
 
 #define PT_MAX_NEE 8        /* light samples per path vertex: point lights + object samples */
 #define PT_MAX_CANDIDATES 8 /* closed candidates of the per-pixel estimator (worker.cpp:183-185) */

@@ -139,6 +139,8 @@ struct pt_scene {
     std::vector<uint32_t> sph_obj;
     uint32_t n_objects = 0;
     uint32_t n_emissive = 0;
+    std::vector<int32_t> emissive_obj;
+    std::vector<float> emissive_cdf;
 
     // device scene
     DevBuf<F4> pairs, tris, tri_nrm, spheres, materials, lights, emis;
@@ -830,6 +832,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         }
         emis.push_back({e[0], e[1], e[2], e[3]});
         cdf.push_back(object_probability);
+        s->emissive_obj.push_back(obj);
     }
     {
         float cumulative_probability = 0.0F;
@@ -843,6 +846,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         }
     }
     s->n_emissive = static_cast<uint32_t>(cdf.size());
+    s->emissive_cdf = cdf;
     const int emissive_object_count = static_cast<int>(cdf.size());
     const int object_sample_count = std::min(2 + static_cast<int>(std::log10(emissive_object_count + 1)), emissive_object_count); // scene.cpp:226
     if(d->n_point_lights + static_cast<uint32_t>(object_sample_count) > PT_MAX_NEE) {
@@ -937,6 +941,25 @@ int pt_scene_info(const pt_scene *scene, uint64_t *n_nodes, uint32_t *depth, uin
     }
     if(n_emissive != nullptr) {
         *n_emissive = scene->n_emissive;
+    }
+    return PT_OK;
+}
+
+int pt_scene_emissive(const pt_scene *scene, int32_t *out_obj, float *out_cdf, uint64_t capacity, uint64_t *n_written) {
+    if(scene == nullptr) {
+        return fail(PT_ERR_INVALID, "null scene");
+    }
+    const uint64_t n = std::min<uint64_t>(scene->emissive_obj.size(), capacity);
+    for(uint64_t i = 0; i < n; i++) {
+        if(out_obj != nullptr) {
+            out_obj[i] = scene->emissive_obj[i];
+        }
+        if(out_cdf != nullptr) {
+            out_cdf[i] = scene->emissive_cdf[i];
+        }
+    }
+    if(n_written != nullptr) {
+        *n_written = scene->emissive_obj.size();
     }
     return PT_OK;
 }

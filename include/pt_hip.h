@@ -130,6 +130,9 @@ void pt_scene_destroy(pt_scene *scene);
 
 /* Introspection for tests: node count of the reference-topology BVH (2 * n_objects - 1), its depth, emissive object count. */
 int pt_scene_info(const pt_scene *scene, uint64_t *n_nodes, uint32_t *depth, uint32_t *n_emissive);
+/* Emissive objects in Scene::registerEmissiveObjects order (scene.cpp:183-208) with their normalised cumulative selection
+ * probabilities (scene.cpp:167-180); at most `capacity` entries are written, the count is returned in *n_written. */
+int pt_scene_emissive(const pt_scene *scene, int32_t *out_obj, float *out_cdf, uint64_t capacity, uint64_t *n_written);
 /* Pre-order dump of the BVH: out_obj[i] = object index of a leaf or -1 for an inner node, out_box[i] = low xyz, high xyz. */
 int pt_scene_bvh_dump(const pt_scene *scene, int32_t *out_obj, float *out_box, uint64_t capacity, uint64_t *n_written);
 

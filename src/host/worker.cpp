@@ -1,0 +1,109 @@
+// src/host/worker.cpp -- processItem / processJob of PathTrace/worker.h on top of the C ABI (include/pt_hip.h).
+#include <PathTrace/worker.h>
+
+#include "../../include/pt_hip.h"
+
+#include <cstdlib>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+    pt_camera_params cameraParams(const Camera &camera) {
+        const Camera::Parameters &p = camera.parameters();
+        if(p.aperture_kind < 0) {
+            throw std::invalid_argument("PathTrace: user-defined ApertureSampler classes cannot be rendered on the device");
+        }
+        pt_camera_params c{};
+        for(int k = 0; k < 3; k++) {
+            c.origin[k] = p.origin[k];
+            c.look_at[k] = p.look_at[k];
+            c.up[k] = p.up[k];
+        }
+        c.focal_length = p.focal_length;
+        c.height = p.height;
+        c.aspect_ratio = p.aspect_ratio;
+        c.aperture_width = p.aperture_width;
+        c.aperture_height = p.aperture_height;
+        c.aperture_kind = p.aperture_kind;
+        c.hex_ratio = p.hex_ratio;
+        c.focal_plane_dist = p.focal_plane_dist;
+        return c;
+    }
+
+    pt_options renderOptions(const RenderOptions &o) {
+        return pt_options{o.image_width, o.image_height, o.min_sample_count, o.max_sample_count, o.epsilon};
+    }
+
+    void check(int status, const char *what) {
+        if(status != PT_OK) {
+            throw std::runtime_error(std::string("PathTrace: ") + what + " failed: " + pt_last_error());
+        }
+    }
+
+} // namespace
+
+WorkItem::WorkItem() noexcept : job(nullptr), offset_x(0), offset_y(0), width(0), height(0) {}
+
+WorkItem::WorkItem(const FrameRenderJob *job, int offset_x, int offset_y, int width, int height) noexcept :
+  job(job), offset_x(offset_x), offset_y(offset_y), width(width), height(height) {}
+
+Image<> processItem(const WorkItem &item, RandomEngine &re) {
+    Image<> tile(item.width, item.height);
+    if(item.width <= 0 || item.height <= 0) {
+        return tile;
+    }
+    const FrameRenderJob &job = *item.job;
+    const pt_camera_params camera = cameraParams(job.camera);
+    const pt_options options = renderOptions(job.options);
+    const pt_stream stream{item.offset_x, item.offset_y, item.width, item.height, re.state()};
+
+    std::vector<float> frame(static_cast<size_t>(options.image_width) * static_cast<size_t>(options.image_height) * 4, 0.0F);
+    uint64_t state_after = stream.rng_state;
+    check(pt_render_streams(job.scene.deviceScene(), &camera, &options, &stream, 1, frame.data(), &state_after, nullptr), "processItem");
+    re.setState(state_after);
+
+    for(int y = 0; y < item.height; y++) {
+        for(int x = 0; x < item.width; x++) {
+            const float *px = &frame[(static_cast<size_t>(item.offset_y + y) * options.image_width + (item.offset_x + x)) * 4];
+            tile(x, y) = Color<float>(px[0], px[1], px[2], px[3]);
+        }
+    }
+    return tile;
+}
+
+Image<> processJob(const FrameRenderJob &job, const std::function<void(int, int)> &progress_callback, int /*worker_count*/) {
+    const int width = std::max(job.options.image_width, 0);
+    const int height = std::max(job.options.image_height, 0);
+    Image<> frame(width, height);
+    if(width == 0 || height == 0) {
+        return frame;
+    }
+    const pt_camera_params camera = cameraParams(job.camera);
+    const pt_options options = renderOptions(job.options);
+
+    std::vector<pt_tile> tiles(pt_job_tiles(width, height, nullptr, 0));
+    pt_job_tiles(width, height, tiles.data(), tiles.size());
+
+    // one random base seed per call, like the reference's std::random_device-seeded workers; $PATHTRACE_SEED pins it
+    uint64_t base_seed;
+    if(const char *fixed = std::getenv("PATHTRACE_SEED")) {
+        base_seed = std::strtoull(fixed, nullptr, 0);
+    }
+    else {
+        std::random_device device;
+        base_seed = (static_cast<uint64_t>(device()) << 32) | device();
+    }
+
+    static_assert(sizeof(Color<float>) == 4 * sizeof(float), "Image<Color<float>> is a packed RGBA float array");
+    check(pt_render_tiles(job.scene.deviceScene(), &camera, &options, tiles.data(), tiles.size(), base_seed, reinterpret_cast<float *>(frame.data()), nullptr),
+          "processJob");
+
+    const int total = static_cast<int>(tiles.size());
+    for(int done = 1; done <= total; done++) {
+        progress_callback(done, total);
+    }
+    return frame;
+}

@@ -1,0 +1,80 @@
+"""The reference-compatible C++ API (include/PathTrace + cpupathtrace_amd/libPathTrace.so).
+
+CPU: the library builds; the reference's OWN unchanged test and demo sources compile and link against it (only in the build
+container, where /root/reference exists); the tests that need no GPU pass.  GPU: the API test program and, if it was built,
+the reference's test binary run in full."""
+import os
+import subprocess
+
+import pytest
+
+from cpupathtrace_amd import build_host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tests", "cpp", "shim")
+REF = "/root/reference"
+REF_OUT = os.path.join(ROOT, "oracle", "_ref")
+GPU_TESTS = "RenderTest,SceneTest"  # tests of the reference's suite that render or query a Scene
+
+
+def _run(exe, skip=None):
+    env = dict(os.environ)
+    if skip:
+        env["PT_TEST_SKIP"] = skip
+    return subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
+
+
+@pytest.fixture(scope="module")
+def api_test_exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("cpp") / "api_test")
+    build_host.compile_program([os.path.join(ROOT, "tests", "cpp", "api_test.cpp")], out, extra_includes=[SHIM], extra_flags=["-O1"])
+    return out
+
+
+def build_reference_programs():
+    """Compile the reference's unchanged test/ and demo/ sources against this repository's include/ (outputs: oracle/_ref/)."""
+    os.makedirs(REF_OUT, exist_ok=True)
+    tests = [os.path.join(REF, "test", f) for f in ("main.cpp", "render_test.cpp", "post_processing_test.cpp", "test_utils.cpp", "scene/boundig_box_test.cpp",
+                                                      "scene/scene_test.cpp", "scene/mesh_test.cpp", "image/image_io_test.cpp")]
+    build_host.compile_program(tests, os.path.join(REF_OUT, "ref_tests"), extra_includes=[SHIM, os.path.join(REF, "test")], extra_flags=["-O1"])
+    build_host.compile_program([os.path.join(REF, "demo", "main.cpp")], os.path.join(REF_OUT, "ref_demo"), extra_flags=["-O1"])
+
+
+def test_host_library_builds_and_links():
+    lib = build_host.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", "-C", lib], capture_output=True, text=True, check=True).stdout
+    for symbol in ("processJob(", "processItem(", "Scene::getIntersection(", "Scene::sampleLights(", "Camera::shootRay(", "makeBox(", "makePlane(",
+                   "io::loadMesh(", "postProcess(", "io::writeRGBImage(", "AABB::getIntersection("):
+        assert symbol in out, symbol
+
+
+def test_api_program_compiles_and_cpu_cases_pass(api_test_exe):
+    r = _run(api_test_exe, skip="Render,Scene,WorkItem")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "[       OK ] Box.SlabTestKnownAnswers" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "test", "render_test.cpp")), reason="reference sources not present")
+def test_reference_sources_compile_unchanged():
+    build_reference_programs()
+    r = _run(os.path.join(REF_OUT, "ref_tests"), skip=GPU_TESTS)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ("PostProcessingTest.GammaTest", "AABBTest.IntersectionTest", "MeshTest.SimpleMeshTest", "ImageIOTest.EncodeDecodeTest"):
+        assert "[       OK ] " + name in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_api_program_on_gpu(api_test_exe):
+    r = _run(api_test_exe)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("[       OK ]") == 8, r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_test_binary_on_gpu():
+    exe = os.path.join(REF_OUT, "ref_tests")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_tests was not built (it is compiled from /root/reference in the build container)")
+    r = _run(exe)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "11 tests, 0 failed" in r.stdout, r.stdout

@@ -15,7 +15,7 @@ from . import build as _build
 from .scenes import MATERIAL_DTYPE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpathtrace_hip.so")
+LIB_PATH = os.environ.get("PT_LIB_OVERRIDE") or os.path.join(HERE, "libpathtrace_hip.so")  # override: A/B builds of the same ABI
 
 PT_OK = 0
 ERRORS = {1: "PT_ERR_INVALID", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR_HIP", 4: "PT_ERR_UNSUPPORTED", 5: "PT_ERR_NOMEM"}

@@ -168,6 +168,7 @@ struct pt_scene {
     DevBuf<uint32_t> tile_offset;
     DevBuf<float> batch_rays;
     DevBuf<uint32_t> walk_hist;
+    DevBuf<unsigned long long> shade_wave_counters, trace_wave_counters;
     // suspended walks: two pools per group
     DevBuf<F4> carry_o, carry_d;
     DevBuf<uint4> carry_state;
@@ -228,6 +229,7 @@ PtPaths make_paths(pt_scene *s, uint32_t n, uint32_t start = 0) {
     P.cand = s->cand.ptr + static_cast<size_t>(start) * PT_MAX_CANDIDATES;
     P.hit = s->hit.ptr + start;
     P.vis = s->vis.ptr + static_cast<size_t>(start) * PT_MAX_NEE;
+    P.wave_counters = s->shade_wave_counters.ptr + 2 * static_cast<size_t>(start / 64);
     return P;
 }
 
@@ -292,6 +294,8 @@ int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot, uint32_t g
     }
     PT_HIP(s->q_header.ensure(static_cast<size_t>(PT_MAX_GROUPS) * 2 * PT_SHARDS * PT_QSTRIDE));
     PT_HIP(s->counters.ensure(PT_MAX_GROUPS));
+    PT_HIP(s->shade_wave_counters.ensure(2 * (static_cast<size_t>(n) / 64 + PT_MAX_GROUPS)));
+    PT_HIP(s->trace_wave_counters.ensure(static_cast<size_t>(s->trace_cfg.grid) * 4 * 4 * groups));
     PT_HIP(s->spill.ensure(static_cast<size_t>(s->trace_cfg.grid) * 256 * s->trace_cfg.spill_depth * groups));
     {
         // room for a quarter of a group's rays to be suspended at once (a full pool only means walks are not suspended)
@@ -451,6 +455,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         const uint64_t blocks = (static_cast<uint64_t>(gr.count) * rays_per_slot + 255) / 256;
         gr.cfg.grid = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(gr.cfg.grid), blocks)));
         gr.cfg.spill = s->spill.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 256 * s->trace_cfg.spill_depth;
+        gr.cfg.wave_counters = s->trace_wave_counters.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 16;
         gr.st = s->group_stream[n_groups];
         gr.done = false;
         n_groups++;
@@ -462,6 +467,8 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     PT_HIP(hipEventCreateWithFlags(&ev_init, hipEventDisableTiming));
     PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters) * PT_MAX_GROUPS, s->stream));
     PT_HIP(hipMemsetAsync(s->carry_header.ptr, 0, static_cast<size_t>(PT_MAX_GROUPS) * 4 * PT_QSTRIDE * sizeof(uint32_t), s->stream));
+    PT_HIP(hipMemsetAsync(s->shade_wave_counters.ptr, 0, s->shade_wave_counters.count * sizeof(unsigned long long), s->stream));
+    PT_HIP(hipMemsetAsync(s->trace_wave_counters.ptr, 0, s->trace_wave_counters.count * sizeof(unsigned long long), s->stream));
     PT_HIP(hipEventRecord(ev_init, s->stream));
     for(Group &gr : G) {
         PT_HIP(hipStreamWaitEvent(gr.st, ev_init, 0));
@@ -568,14 +575,20 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         float total = 0.0F;
         PT_HIP(hipEventElapsedTime(&total, ev_begin, ev_end));
         PtDevCounters c{};
-        for(size_t g = 0; g < G.size(); g++) {
-            const PtDevCounters &h = s->host_counters[g];
-            c.samples += h.samples;
-            c.rays += h.rays;
-            c.shadow_rays += h.shadow_rays;
-            c.node_visits += h.node_visits;
-            c.leaf_tests += h.leaf_tests;
-            c.vertices += h.vertices;
+        {
+            std::vector<unsigned long long> shade_slots(s->shade_wave_counters.count), trace_slots(s->trace_wave_counters.count);
+            PT_HIP(hipMemcpy(shade_slots.data(), s->shade_wave_counters.ptr, shade_slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            PT_HIP(hipMemcpy(trace_slots.data(), s->trace_wave_counters.ptr, trace_slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for(size_t i = 0; i + 1 < shade_slots.size(); i += 2) {
+                c.samples += shade_slots[i];
+                c.vertices += shade_slots[i + 1];
+            }
+            for(size_t i = 0; i + 3 < trace_slots.size(); i += 4) {
+                c.node_visits += trace_slots[i];
+                c.leaf_tests += trace_slots[i + 1];
+                c.rays += trace_slots[i + 2];
+                c.shadow_rays += trace_slots[i + 3];
+            }
         }
         stats->samples = c.samples;
         stats->rays_traced = c.rays;
@@ -1014,6 +1027,7 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
     trace_cfg.grid = static_cast<int>(std::max<uint32_t>(1U, std::min<uint32_t>(static_cast<uint32_t>(trace_cfg.grid), (n32 + 255U) / 256U)));
     trace_cfg.max_steps = 0x7fffffff;
     trace_cfg.parity = 0;
+    trace_cfg.wave_counters = s->trace_wave_counters.ptr;
     PT_HIP(hipMemsetAsync(s->carry_header.ptr, 0, 4 * PT_QSTRIDE * sizeof(uint32_t), st));
     PtCarry carry = make_carry(s, 0);
     carry.cap = 0;

@@ -32,6 +32,7 @@ struct PtPaths {
     // results of the traversal kernel
     uint2 *hit;            // [n] (bits t, ref) of the extension ray
     uint32_t *vis;         // [n][PT_MAX_NEE] 1 = shadow ray unoccluded
+    unsigned long long *wave_counters; // [ceil(n / 64)][2] samples finished, vertices shaded (plain adds, one slot per wave)
 };
 
 #define PT_F_DONE 1u      /* the stream has rendered all its pixels */
@@ -80,6 +81,7 @@ struct PtTraceConfig {
     uint32_t *walk_hist;  // optional [33] histogram of inner-node steps per finished walk (PT_WALK_HIST=1), else null
     int max_steps;        // inner-node steps a walk may take in one launch before it is suspended
     int parity;           // this launch resumes pool `parity` and suspends into pool `parity ^ 1`
+    unsigned long long *wave_counters; // [grid * 4 waves][4] node visits, leaf tests, rays, shadow rays (plain adds, one slot per wave)
 };
 
 void pt_launch_init_tiles(hipStream_t stream, PtPaths paths, const int4 *tiles, const uint32_t *tile_offset, uint32_t n_tiles, uint64_t base_seed);

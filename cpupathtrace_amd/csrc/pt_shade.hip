@@ -292,7 +292,10 @@ PT_D bool sample_emissive(const PtDevScene &sc, V3 pos, uint64_t &rng, V3 &light
 
 // ---- the kernel -------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamera cam, PtDevOptions opt, PtPaths P, PtQueue q, PtCarry carry, int parity,
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 3
+#endif
+__global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScene sc, PtDevCamera cam, PtDevOptions opt, PtPaths P, PtQueue q, PtCarry carry, int parity,
                                                        float4 *__restrict__ image, PtDevCounters *counters) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -644,14 +647,15 @@ __global__ __launch_bounds__(256) void pt_shade_kernel(PtDevScene sc, PtDevCamer
         }
     }
 
-    // counters: one atomic per wave
+    // counters: one slot per wave, plain adds (see pt_trace.hip)
     for(int off = 32; off > 0; off >>= 1) {
         n_samples += __shfl_down(n_samples, off);
         n_vertices += __shfl_down(n_vertices, off);
     }
     if(lane == 0 && (n_samples | n_vertices)) {
-        atomicAdd(&counters->samples, n_samples);
-        atomicAdd(&counters->vertices, n_vertices);
+        unsigned long long *slot = P.wave_counters + 2 * (size_t)(p >> 6);
+        slot[0] += n_samples;
+        slot[1] += n_vertices;
     }
 }
 

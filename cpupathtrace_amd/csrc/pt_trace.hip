@@ -76,7 +76,7 @@ template<int STACK_LDS, int LDS_MODE, bool COUNT>
 __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, PtCarry carry, int parity, int max_steps, uint2 *__restrict__ hit,
                                                        uint32_t *__restrict__ vis,
                                                        uint2 *__restrict__ spill, uint32_t spill_depth, int refill_idle, int leaf_min,
-                                                       PtDevCounters *counters, uint32_t *walk_hist) {
+                                                       unsigned long long *__restrict__ wave_counters, uint32_t *walk_hist) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     uint2 *lds_stack = reinterpret_cast<uint2 *>(lds_raw);
     float4 *lds_pairs = reinterpret_cast<float4 *>(lds_raw + (size_t)STACK_LDS * 256 * sizeof(uint2));
@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     }
 
     if(COUNT) {
-        // one atomic per wave and counter
+        // Work counters: every wave owns one 32-byte slot and adds its totals with plain stores.  (Atomics on one shared line
+        // from every wave of the grid serialise at the memory side -- about 40 ns each -- and were a visible part of the launch.)
         for(int off = 32; off > 0; off >>= 1) {
             n_nodes += __shfl_down(n_nodes, off);
             n_leaves += __shfl_down(n_leaves, off);
@@ -447,10 +448,11 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             n_shadow += __shfl_down(n_shadow, off);
         }
         if(lane == 0) {
-            atomicAdd(&counters->node_visits, (unsigned long long)n_nodes);
-            atomicAdd(&counters->leaf_tests, (unsigned long long)n_leaves);
-            atomicAdd(&counters->rays, (unsigned long long)n_rays);
-            atomicAdd(&counters->shadow_rays, (unsigned long long)n_shadow);
+            unsigned long long *slot = wave_counters + 4 * ((size_t)blockIdx.x * 4 + (tid >> 6));
+            slot[0] += n_nodes;
+            slot[1] += n_leaves;
+            slot[2] += n_rays;
+            slot[3] += n_shadow;
         }
     }
 }
@@ -480,7 +482,7 @@ void launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, Pt
                   PtDevCounters *counters) {
     hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, LDS_MODE, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, carry, cfg.parity, cfg.max_steps, paths.hit,
                        paths.vis,
-                       cfg.spill, cfg.spill_depth, cfg.refill_idle, cfg.leaf_min, counters, cfg.walk_hist);
+                       cfg.spill, cfg.spill_depth, cfg.refill_idle, cfg.leaf_min, cfg.wave_counters, cfg.walk_hist);
 }
 
 template<int STACK_LDS>

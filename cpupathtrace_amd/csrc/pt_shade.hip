@@ -16,8 +16,8 @@
 // flight and every draw of a vertex (roulette, lights, BSDF) is made by the single invocation that shades the vertex.
 //
 // Rays are appended to the queue shard of this workgroup (blockIdx.x % 8): each lane reserves its worst case
-// (1 extension ray + L + k shadow rays) and the wave makes ONE atomic for all lanes, lane offsets coming from
-// ballot/popcount prefix sums; light samples that turn out not to need a ray leave a PT_DEST_NULL hole.
+// (1 extension ray + L + k shadow rays) and the workgroup makes ONE atomic for all its lanes, lane offsets coming from
+// ballot/popcount prefix sums and a per-wave table in LDS; light samples that turn out not to need a ray leave a PT_DEST_NULL hole.
 #include "pt_device.h"
 #include "pt_kernels.h"
 
@@ -504,17 +504,27 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScen
         emit_ext = do_bounce || safe_overlap;
     }
 
-    // ---- reserve queue space: one atomic per wave -----------------------------------------------------------------------------
+    // ---- reserve queue space: one atomic per workgroup ----------------------------------------------------------------------------
+    // lane offsets come from ballot/popcount prefix sums, wave offsets from a 4-entry LDS table; thread 0 makes the one atomic
+    __shared__ uint32_t wave_totals[4];
+    __shared__ uint32_t block_base;
     const unsigned long long ext_mask = __ballot(emit_ext);
     const unsigned long long nee_mask_w = __ballot(want_nee);
     const unsigned long long lt = (1ULL << lane) - 1ULL;
     const uint32_t wave_total = (uint32_t)__popcll(ext_mask) + n_light_samples * (uint32_t)__popcll(nee_mask_w);
-    uint32_t wave_base = 0;
-    if(wave_total > 0) {
-        if(lane == 0) {
-            wave_base = atomicAdd(&q.count[shard * PT_QSTRIDE], wave_total);
-        }
-        wave_base = __builtin_amdgcn_readfirstlane(wave_base);
+    const int wave = threadIdx.x >> 6;
+    if(lane == 0) {
+        wave_totals[wave] = wave_total;
+    }
+    __syncthreads();
+    if(threadIdx.x == 0) {
+        const uint32_t total = wave_totals[0] + wave_totals[1] + wave_totals[2] + wave_totals[3];
+        block_base = total > 0 ? atomicAdd(&q.count[shard * PT_QSTRIDE], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t wave_base = block_base;
+    for(int w = 0; w < wave; w++) {
+        wave_base += wave_totals[w];
     }
     const size_t slot0 = (size_t)shard * q.shard_capacity + wave_base + (uint32_t)__popcll(ext_mask & lt) + n_light_samples * (uint32_t)__popcll(nee_mask_w & lt);
     // this lane's extension ray goes to slot0, its shadow rays to slot0 + (emit_ext ? 1 : 0) + j

@@ -433,6 +433,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         bool done;
     };
     std::vector<Group> G(groups);
+    const int shard_mode = env_int("PT_SHARD_MODE", 1);
     const int max_steps_env = env_int("PT_MAX_STEPS", 256);
     const int max_steps = max_steps_env > 0 ? max_steps_env : 0x7fffffff;
     const uint32_t per_group = ((n + groups - 1) / groups + 2047U) / 2048U * 2048U;
@@ -518,7 +519,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
                 }
                 const int parity = static_cast<int>(iterations & 1U);
                 gr.cfg.parity = parity;
-                pt_launch_shade(gr.st, s->dev, cam, opt, gr.P, gr.q, gr.carry, parity, d_image, cnt);
+                pt_launch_shade(gr.st, s->dev, cam, opt, gr.P, gr.q, gr.carry, parity, shard_mode, d_image, cnt);
                 if(timing) {
                     PT_HIP(hipEventRecord(ev[4 * pending + 1], gr.st));
                     PT_HIP(hipEventRecord(ev[4 * pending + 2], gr.st));

@@ -296,10 +296,12 @@ PT_D bool sample_emissive(const PtDevScene &sc, V3 pos, uint64_t &rng, V3 &light
 #define PT_SHADE_WAVES 3
 #endif
 __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScene sc, PtDevCamera cam, PtDevOptions opt, PtPaths P, PtQueue q, PtCarry carry, int parity,
-                                                       float4 *__restrict__ image, PtDevCounters *counters) {
+                                                       int shard_mode, float4 *__restrict__ image, PtDevCounters *counters) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const uint32_t shard = blockIdx.x % PT_SHARDS;
+    // Contiguous eighths of the streams (= contiguous image regions) feed one queue shard each; the traversal workgroups of one
+    // XCD drain one shard first, so the subtrees a region's rays walk stay in that XCD's L2.  (shard_mode 0: round-robin.)
+    const uint32_t shard = shard_mode != 0 ? (uint32_t)(((unsigned long long)blockIdx.x * PT_SHARDS) / gridDim.x) : blockIdx.x % PT_SHARDS;
     const uint32_t n_light_samples = sc.n_lights + sc.n_object_samples;
 
     if(p == 0) {
@@ -730,9 +732,9 @@ void pt_launch_init_streams(hipStream_t stream, PtPaths paths) {
 }
 
 void pt_launch_shade(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtPaths paths, PtQueue queue,
-                     PtCarry carry, int parity, float4 *image, PtDevCounters *counters) {
+                     PtCarry carry, int parity, int shard_mode, float4 *image, PtDevCounters *counters) {
     if(paths.n == 0) {
         return;
     }
-    hipLaunchKernelGGL(pt_shade_kernel, dim3((paths.n + 255) / 256), dim3(256), 0, stream, scene, camera, options, paths, queue, carry, parity, image, counters);
+    hipLaunchKernelGGL(pt_shade_kernel, dim3((paths.n + 255) / 256), dim3(256), 0, stream, scene, camera, options, paths, queue, carry, parity, shard_mode, image, counters);
 }

@@ -91,10 +91,14 @@ def cpu_baseline(sc, cam, opt, seconds_target):
         h.render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=threads)
         return time.time() - t
 
-    n0 = max(4 * threads, 64)
-    t_probe = run(n0)
-    n1 = int(min(max(n0 * seconds_target / max(t_probe, 1e-3), n0), 4_000_000))
+    # grow the sample until it runs for about the requested time (the first, tiny run also pays thread start-up and page faults)
+    n1 = max(4 * threads, 64)
     t_run = run(n1)
+    for _ in range(4):
+        if t_run >= 0.6 * seconds_target:
+            break
+        n1 = int(min(max(n1 * min(seconds_target / max(t_run, 1e-3), 20.0), n1 + 1), 4_000_000))
+        t_run = run(n1)
     counters = None
     if kind == "port":
         counters = h.counters()

@@ -345,8 +345,12 @@ int setup_trace(pt_scene *s) {
     cfg.grid = s->cu_count * ((limit > 0 && limit < per_cu) ? limit : per_cu);
     cfg.spill_depth = s->tree.depth > static_cast<uint32_t>(stack_lds) ? s->tree.depth - static_cast<uint32_t>(stack_lds) : 1U;
     cfg.spill = nullptr; // allocated with the workspace (one area per group)
-    cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 20), 1), 64);
+    // measured (profiles/): short LDS-resident walks want few dequeue atomics (256 rays each, refill at 20 idle lanes); long walks
+    // through HBM-resident trees want fine-grained balancing between wavefronts (96 rays, refill at 12)
+    const bool small_scene = cfg.lds_mode == 2;
+    cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", small_scene ? 20 : 12), 1), 64);
     cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 1), 1), 64);
+    cfg.chunk = std::min(std::max(env_int("PT_QCHUNK", small_scene ? 256 : 96), 16), 4096);
     if(env_int("PT_DEBUG", 0) != 0) {
         std::fprintf(stderr, "[pt] trace config: grid %d (%d CUs x %d blocks), stack_lds %d, lds mode %d, lds %zu B, spill depth %u, lds pairs %u, lds tris %u\n", cfg.grid,
                      s->cu_count, per_cu, stack_lds, cfg.lds_mode, cfg.lds_bytes, cfg.spill_depth, s->dev.n_lds_pairs, s->dev.n_lds_tris);
@@ -434,6 +438,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     };
     std::vector<Group> G(groups);
     const int shard_mode = env_int("PT_SHARD_MODE", 1);
+    const int drain_lanes = std::min(std::max(env_int("PT_DRAIN_LANES", 16), 0), 64);
     const int max_steps_env = env_int("PT_MAX_STEPS", 256);
     const int max_steps = max_steps_env > 0 ? max_steps_env : 0x7fffffff;
     const uint32_t per_group = ((n + groups - 1) / groups + 2047U) / 2048U * 2048U;
@@ -452,6 +457,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         gr.carry = make_carry(s, n_groups);
         gr.cfg = s->trace_cfg;
         gr.cfg.max_steps = max_steps;
+        gr.cfg.drain_lanes = drain_lanes;
         // no more workgroups than the rays one iteration can produce
         const uint64_t blocks = (static_cast<uint64_t>(gr.count) * rays_per_slot + 255) / 256;
         gr.cfg.grid = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(gr.cfg.grid), blocks)));
@@ -1027,6 +1033,7 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
     trace_cfg.spill = s->spill.ptr;
     trace_cfg.grid = static_cast<int>(std::max<uint32_t>(1U, std::min<uint32_t>(static_cast<uint32_t>(trace_cfg.grid), (n32 + 255U) / 256U)));
     trace_cfg.max_steps = 0x7fffffff;
+    trace_cfg.drain_lanes = 0;
     trace_cfg.parity = 0;
     trace_cfg.wave_counters = s->trace_wave_counters.ptr;
     PT_HIP(hipMemsetAsync(s->carry_header.ptr, 0, 4 * PT_QSTRIDE * sizeof(uint32_t), st));

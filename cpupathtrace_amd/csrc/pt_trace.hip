@@ -73,7 +73,8 @@ PT_D float slab_walk(V3 lo, V3 hi, V3 o, V3 inv) {
 //           1 = records with index < n_lds_* come from LDS, the rest from HBM (breadth-first top of the tree),
 //           2 = the whole tree and all triangles are in LDS (small scenes).
 template<int STACK_LDS, int LDS_MODE, bool COUNT>
-__global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, PtCarry carry, int parity, int max_steps, uint2 *__restrict__ hit,
+__global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, PtCarry carry, int parity, int max_steps, int drain_lanes, int chunk,
+                                                       uint2 *__restrict__ hit,
                                                        uint32_t *__restrict__ vis,
                                                        uint2 *__restrict__ spill, uint32_t spill_depth, int refill_idle, int leaf_min,
                                                        unsigned long long *__restrict__ wave_counters, uint32_t *walk_hist) {
@@ -154,12 +155,12 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 if(!carry_done) {
                     uint32_t base = 0;
                     if(lane == 0) {
-                        base = atomicAdd(&carry.head[carry_in * PT_QSTRIDE], (uint32_t)PT_QCHUNK);
+                        base = atomicAdd(&carry.head[carry_in * PT_QSTRIDE], (uint32_t)chunk);
                     }
                     base = __builtin_amdgcn_readfirstlane(base);
                     if(base < carry_count) {
                         res_next = carry_in * carry.cap + base;
-                        res_end = res_next + (carry_count - base < PT_QCHUNK ? carry_count - base : (uint32_t)PT_QCHUNK);
+                        res_end = res_next + (carry_count - base < (uint32_t)chunk ? carry_count - base : (uint32_t)chunk);
                         res_is_carry = true;
                     }
                     else {
@@ -173,12 +174,12 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                     if(__hip_atomic_load(&q.head[shard * PT_QSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < count) {
                         uint32_t base = 0;
                         if(lane == 0) {
-                            base = atomicAdd(&q.head[shard * PT_QSTRIDE], (uint32_t)PT_QCHUNK);
+                            base = atomicAdd(&q.head[shard * PT_QSTRIDE], (uint32_t)chunk);
                         }
                         base = __builtin_amdgcn_readfirstlane(base);
                         if(base < count) {
                             res_next = shard * q.shard_capacity + base;
-                            res_end = res_next + (count - base < PT_QCHUNK ? count - base : (uint32_t)PT_QCHUNK);
+                            res_end = res_next + (count - base < (uint32_t)chunk ? count - base : (uint32_t)chunk);
                             break;
                         }
                     }
@@ -338,7 +339,13 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
 
         // ---- 3b. suspend walks that used up this launch's step budget -------------------------------------------------------------
         {
-            const bool over = active && cur != PT_REF_NONE && (n_nodes - walk_start) >= (uint32_t)max_steps;
+            // ... and, once the queue has nothing left for this wavefront, the last few walks of the wave (after at least 32 steps
+            // each, so every walk makes progress in every launch): the launch then ends with the bulk of the rays instead of
+            // idling the chip behind a handful of long walks; those resume first in the next launch.
+            const bool draining = exhausted && carry_done && res_next >= res_end;
+            const uint32_t steps_here = n_nodes - walk_start;
+            const bool few_left = draining && __popcll(__ballot(active)) <= drain_lanes;
+            const bool over = active && cur != PT_REF_NONE && (steps_here >= (uint32_t)max_steps || (few_left && steps_here >= 32u));
             const unsigned long long over_mask = __ballot(over);
             if(over_mask != 0ULL) {
                 uint32_t base = 0;
@@ -480,7 +487,7 @@ __global__ void pt_batch_rays_kernel(const float *__restrict__ rays6, uint32_t n
 template<int STACK_LDS, int LDS_MODE>
 void launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtCarry carry, PtPaths paths, const PtTraceConfig &cfg,
                   PtDevCounters *counters) {
-    hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, LDS_MODE, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, carry, cfg.parity, cfg.max_steps, paths.hit,
+    hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, LDS_MODE, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, carry, cfg.parity, cfg.max_steps, cfg.drain_lanes, cfg.chunk, paths.hit,
                        paths.vis,
                        cfg.spill, cfg.spill_depth, cfg.refill_idle, cfg.leaf_min, cfg.wave_counters, cfg.walk_hist);
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the hot path (processJob) on N MI355X, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dragon|cornell|box] [--spp S] [--mesh-n M]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dragon|dragons16|cornell|box] [--spp S] [--mesh-n M]
 
 Metric (BASELINE.json / reference benchmark/main.cpp:20,30): Msamples/s = image_width * image_height * spp / wall seconds
 of processJob with min_sample_count == max_sample_count == spp; one sample = one camera path with all its bounces and
@@ -49,6 +49,10 @@ def build_workload(name, width, height, mesh_n):
         pos, nrm = scenes.bumpy_sphere_mesh(mesh_n, mesh_n, scenes.DRAGON_BOX_TRANSFORM)
         sc, cam = scenes.dragon_box_scene(pos, nrm, aspect_ratio=aspect)
         label = "DragonBox (benchmark/main.cpp:59-105), procedural %d-triangle glass mesh standing in for xyzrgb_dragon.obj" % len(pos)
+    elif name == "dragons16":
+        pos, nrm = scenes.bumpy_sphere_mesh(mesh_n, mesh_n, scenes.DRAGON_BOX_TRANSFORM)
+        sc, cam = scenes.dragon_grid_scene(pos, nrm, aspect_ratio=aspect, grid=4)
+        label = "16 transformed copies of the %d-triangle stand-in mesh (%d triangles) in an enlarged box (BASELINE.json configs[4])" % (len(pos), 16 * len(pos))
     elif name == "cornell":
         sc, cam = scenes.cornell_scene(width, height)
         label = "Cornell box of demo/main.cpp without the dragon (27 objects), thin-lens camera"

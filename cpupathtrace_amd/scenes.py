@@ -248,6 +248,24 @@ def dragon_box_scene(mesh_pos, mesh_nrm, aspect_ratio=-1.0, copies=1):
     return sb.build(), camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, aspect_ratio)
 
 
+def dragon_grid_scene(mesh_pos, mesh_nrm, aspect_ratio=-1.0, grid=4):
+    """BASELINE.json configs[4]: grid x grid transformed COPIES of the mesh (the reference has no instancing: every copy is its
+    own set of Triangle objects) on the floor of an enlarged box, same light and camera layout as DragonBox."""
+    sb = SceneBuilder()
+    half = F(grid)  # box half-extent: one unit cell per copy
+    sb.triangles(make_box((-half, -1.0, -half), (half, 1.0, half)))
+    light = sb.material((1, 1, 1, 1), 1.0, (1, 1, 1, 1))
+    sb.triangles(make_plane((-0.25 * grid, F(1.0) - F(0.01), -0.25 * grid), (0.25 * grid, F(1.0) - F(0.01), 0.25 * grid)), light, cull=True)
+    glass = sb.material((1, 1, 1, 1), 1.5, bsdf=BSDF_GLASS)
+    pos = np.asarray(mesh_pos, dtype=F).reshape(-1, 3, 3)
+    for gz in range(grid):
+        for gx in range(grid):
+            shift = np.array([F(2 * gx + 1) - half, 0, F(2 * gz + 1) - half], dtype=F)
+            sb.triangles(pos + shift, glass, cull=False, normals=mesh_nrm)
+    cam = camera((0, 0.5, -3.0 * grid), (0, -0.3, 0), (0, 1, 0), 1.0, 1.0, aspect_ratio)
+    return sb.build(), cam
+
+
 DRAGON_BOX_TRANSFORM = [[0.01, 0, 0, 0], [0, 0.01, 0, -0.5], [0, 0, 0.01, 0], [0, 0, 0, 1]]  # benchmark/main.cpp:80-83
 DEMO_DRAGON_TRANSFORM = [[0.005, 0, 0, 0.4], [0, 0.005, 0, -0.8], [0, 0, 0.005, -0.75], [0, 0, 0, 1]]  # demo/main.cpp:141-144
 

@@ -1,0 +1,64 @@
+// src/host/c_exports.cpp -- plain-C views of a few scene-construction helpers of libPathTrace.so, so the Python test-suite can
+// compare them with the compiled reference (tests/test_oracle_vs_reference.py).  Same argument lists as the matching
+// functions of oracle/ref_shim.cpp.
+#include <PathTrace/scene/mesh.h>
+
+#include <cstdint>
+#include <sstream>
+#include <string>
+
+namespace {
+
+    uint64_t store(const std::vector<Triangle> &triangles, uint64_t capacity, float *pos, float *nrm) {
+        for(uint64_t i = 0; i < triangles.size() && i < capacity; i++) {
+            const Triangle &t = triangles[i];
+            const vec3<float> *points[3] = {&t.a, &t.b, &t.c};
+            const vec3<float> *normals[3] = {&t.normal_a, &t.normal_b, &t.normal_c};
+            for(int v = 0; v < 3; v++) {
+                for(int k = 0; k < 3; k++) {
+                    pos[9 * i + 3 * v + k] = (*points[v])[k];
+                    nrm[9 * i + 3 * v + k] = (*normals[v])[k];
+                }
+            }
+        }
+        return triangles.size();
+    }
+
+    mat4<float> matrixFrom(const float *m16) {
+        mat4<float> m{};
+        for(int r = 0; r < 4; r++) {
+            for(int c = 0; c < 4; c++) {
+                m.rows[r][c] = m16[4 * r + c];
+            }
+        }
+        return m;
+    }
+
+} // namespace
+
+extern "C" {
+
+uint64_t pth_make_plane(const float *a, const float *b, uint64_t capacity, float *pos, float *nrm) {
+    return store(makePlane(vec3<float>(a[0], a[1], a[2]), vec3<float>(b[0], b[1], b[2]), false), capacity, pos, nrm);
+}
+
+uint64_t pth_make_box(const float *a, const float *b, uint64_t capacity, float *pos, float *nrm) {
+    return store(makeBox(vec3<float>(a[0], a[1], a[2]), vec3<float>(b[0], b[1], b[2]), false), capacity, pos, nrm);
+}
+
+uint64_t pth_load_mesh(const char *obj_text, uint64_t len, const float *mat16, int smooth, uint64_t capacity, float *pos, float *nrm) {
+    std::istringstream stream(std::string(obj_text, len));
+    return store(io::loadMesh(stream, matrixFrom(mat16), false, smooth != 0), capacity, pos, nrm);
+}
+
+void pth_mat4_apply(const float *mat16, uint64_t n, const float *in, float *out) {
+    const mat4<float> m = matrixFrom(mat16);
+    for(uint64_t i = 0; i < n; i++) {
+        const auto v = m * vec3<float>(in[3 * i], in[3 * i + 1], in[3 * i + 2]);
+        out[3 * i] = v[0];
+        out[3 * i + 1] = v[1];
+        out[3 * i + 2] = v[2];
+    }
+}
+
+}

@@ -351,6 +351,7 @@ int setup_trace(pt_scene *s) {
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", small_scene ? 20 : 12), 1), 64);
     cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 1), 1), 64);
     cfg.chunk = std::min(std::max(env_int("PT_QCHUNK", small_scene ? 256 : 96), 16), 4096);
+    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 4), 1), 64);
     if(env_int("PT_DEBUG", 0) != 0) {
         std::fprintf(stderr, "[pt] trace config: grid %d (%d CUs x %d blocks), stack_lds %d, lds mode %d, lds %zu B, spill depth %u, lds pairs %u, lds tris %u\n", cfg.grid,
                      s->cu_count, per_cu, stack_lds, cfg.lds_mode, cfg.lds_bytes, cfg.spill_depth, s->dev.n_lds_pairs, s->dev.n_lds_tris);

@@ -82,6 +82,7 @@ struct PtTraceConfig {
     int max_steps;        // inner-node steps a walk may take in one launch before it is suspended
     int parity;           // this launch resumes pool `parity` and suspends into pool `parity ^ 1`
     int chunk;            // rays a wavefront reserves per dequeue atomic
+    int burst_steps;      // inner-node steps between two looks at the leaves / the queue
     int drain_lanes;      // with the queue empty, a wavefront with at most this many walks left suspends them (0: never)
     unsigned long long *wave_counters; // [grid * 4 waves][4] node visits, leaf tests, rays, shadow rays (plain adds, one slot per wave)
 };

@@ -26,8 +26,8 @@
 //     lane; the breadth-first top of the tree and, for small scenes, the triangle records are staged in LDS once per
 //     workgroup; everything else is a random HBM/L2 fetch -- the kernel is bound by memory latency/bandwidth, there is no
 //     matrix work in it (no MFMA);
-//   * the traversal stack lives in LDS ([level][lane] layout: conflict-free ds_read_b64/ds_write_b64), with the rare
-//     overflow beyond PT_STACK_LDS levels going to a per-lane HBM spill area.
+//   * the traversal stack lives in LDS ([slot][lane] layout: conflict-free ds_read_b64/ds_write_b64) as a window over the
+//     top STACK_LDS entries, with older entries of unusually deep walks in a per-lane HBM spill area.
 #include "pt_device.h"
 #include "pt_kernels.h"
 
@@ -73,7 +73,7 @@ PT_D float slab_walk(V3 lo, V3 hi, V3 o, V3 inv) {
 //           1 = records with index < n_lds_* come from LDS, the rest from HBM (breadth-first top of the tree),
 //           2 = the whole tree and all triangles are in LDS (small scenes).
 template<int STACK_LDS, int LDS_MODE, bool COUNT>
-__global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, PtCarry carry, int parity, int max_steps, int drain_lanes, int chunk,
+__global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, PtCarry carry, int parity, int max_steps, int drain_lanes, int chunk, int burst_steps,
                                                        uint2 *__restrict__ hit,
                                                        uint32_t *__restrict__ vis,
                                                        uint2 *__restrict__ spill, uint32_t spill_depth, int refill_idle, int leaf_min,
@@ -103,6 +103,33 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     lds_f4_cptr tris_l = (lds_f4_cptr)lds_tris;
     glb_f4_cptr pairs_g = (glb_f4_cptr)sc.pairs;
     glb_f4_cptr tris_g = (glb_f4_cptr)sc.tris;
+
+    // The traversal stack: the top STACK_LDS entries of a lane live in LDS (slot = index mod STACK_LDS), older ones in the
+    // lane's HBM spill area.  Pushing onto a full window first moves the entry that is about to be overwritten to HBM;
+    // popping from a deep stack brings it back.  Walks rarely go deeper than the window, so the common path is one LDS
+    // access without any branching between address spaces.
+    auto stack_push = [&](int &sp_, uint32_t ref, float entry_t) {
+        const int slot = (sp_ % STACK_LDS) * 256 + tid;
+        if(sp_ >= STACK_LDS) {
+            my_spill[sp_ - STACK_LDS] = stack_l[slot];
+        }
+        const u2v ev = {ref, __float_as_uint(entry_t)};
+        stack_l[slot] = ev;
+        sp_++;
+    };
+    auto stack_pop = [&](int &sp_) -> u2v {
+        sp_--;
+        const int slot = (sp_ % STACK_LDS) * 256 + tid;
+        const u2v e = stack_l[slot];
+        if(sp_ >= STACK_LDS) {
+            stack_l[slot] = my_spill[sp_ - STACK_LDS];
+        }
+        return e;
+    };
+    // entry i of a stack of depth sp_ (for suspending a walk)
+    auto stack_peek = [&](int sp_, int i) -> u2v {
+        return (i >= sp_ - STACK_LDS) ? stack_l[(i % STACK_LDS) * 256 + tid] : my_spill[i];
+    };
 
     // wave-uniform queue cursor
     uint32_t shard = blockIdx.x % PT_SHARDS;
@@ -214,11 +241,11 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                     for(int i = 0; i < sp; i++) {
                         const uint2 e = saved[i];
                         const u2v ev = {e.x, e.y};
-                        if(i < STACK_LDS) {
-                            stack_l[i * 256 + tid] = ev;
+                        if(i >= sp - STACK_LDS) {
+                            stack_l[(i % STACK_LDS) * 256 + tid] = ev;
                         }
                         else {
-                            my_spill[i - STACK_LDS] = ev;
+                            my_spill[i] = ev;
                         }
                     }
                     active = true;
@@ -265,7 +292,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
         // ---- 3. inner nodes: a burst of steps for the lanes standing on an inner node -----------------------------------------
         // Lanes that reach a leaf wait (their order of visits is unchanged) until enough of them can share the leaf code.
 #pragma unroll 1
-        for(int burst = 0; burst < 4; burst++) {
+        for(int burst = 0; burst < burst_steps; burst++) {
             const bool on_inner = active && !(cur & PT_REF_LEAF);
             if(__ballot(on_inner) == 0ULL) {
                 break;
@@ -300,34 +327,14 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 const uint32_t far_ref = left_close ? right_ref : left_ref;
                 const bool go_close = close_t >= 0.0f && close_t < t_max;
                 const bool go_far = far_t >= 0.0f && far_t < t_max;
-                if(go_close) {
-                    if(go_far) {
-                        const u2v ev = {far_ref, __float_as_uint(far_t)};
-                        if(sp < STACK_LDS) {
-                            stack_l[sp * 256 + tid] = ev;
-                        }
-                        else {
-                            my_spill[sp - STACK_LDS] = ev;
-                        }
-                        sp++;
-                    }
-                    cur = close_ref;
+                if(go_close && go_far) {
+                    stack_push(sp, far_ref, far_t);
                 }
-                else if(go_far) {
-                    cur = far_ref;
-                }
-                else {
+                cur = go_close ? close_ref : (go_far ? far_ref : PT_REF_NONE);
+                if(!go_close && !go_far) {
                     // pop: the first parked node whose entry distance is still below t_max
-                    cur = PT_REF_NONE;
                     while(sp > 0) {
-                        sp--;
-                        u2v e;
-                        if(sp < STACK_LDS) {
-                            e = stack_l[sp * 256 + tid];
-                        }
-                        else {
-                            e = my_spill[sp - STACK_LDS];
-                        }
+                        const u2v e = stack_pop(sp);
                         if(__uint_as_float(e.y) < t_max) {
                             cur = e.x;
                             break;
@@ -362,13 +369,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                     carry.sp[c] = (uint32_t)sp;
                     uint2 *saved = carry.stack + (size_t)c * carry.depth;
                     for(int i = 0; i < sp; i++) {
-                        u2v e;
-                        if(i < STACK_LDS) {
-                            e = stack_l[i * 256 + tid];
-                        }
-                        else {
-                            e = my_spill[i - STACK_LDS];
-                        }
+                        const u2v e = stack_peek(sp, i);
                         saved[i] = make_uint2(e.x, e.y);
                     }
                     active = false;
@@ -427,14 +428,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 else {
                     cur = PT_REF_NONE;
                     while(sp > 0) {
-                        sp--;
-                        u2v e;
-                        if(sp < STACK_LDS) {
-                            e = stack_l[sp * 256 + tid];
-                        }
-                        else {
-                            e = my_spill[sp - STACK_LDS];
-                        }
+                        const u2v e = stack_pop(sp);
                         if(__uint_as_float(e.y) < t_max) {
                             cur = e.x;
                             break;
@@ -487,7 +481,7 @@ __global__ void pt_batch_rays_kernel(const float *__restrict__ rays6, uint32_t n
 template<int STACK_LDS, int LDS_MODE>
 void launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtCarry carry, PtPaths paths, const PtTraceConfig &cfg,
                   PtDevCounters *counters) {
-    hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, LDS_MODE, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, carry, cfg.parity, cfg.max_steps, cfg.drain_lanes, cfg.chunk, paths.hit,
+    hipLaunchKernelGGL((pt_trace_kernel<STACK_LDS, LDS_MODE, true>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, queue, carry, cfg.parity, cfg.max_steps, cfg.drain_lanes, cfg.chunk, cfg.burst_steps, paths.hit,
                        paths.vis,
                        cfg.spill, cfg.spill_depth, cfg.refill_idle, cfg.leaf_min, cfg.wave_counters, cfg.walk_hist);
 }

@@ -440,6 +440,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     std::vector<Group> G(groups);
     const int shard_mode = env_int("PT_SHARD_MODE", 1);
     const int drain_lanes = std::min(std::max(env_int("PT_DRAIN_LANES", 16), 0), 64);
+    const int endgame_percent = std::min(std::max(env_int("PT_ENDGAME_PERCENT", 90), 1), 101);
     const int max_steps_env = env_int("PT_MAX_STEPS", 256);
     const int max_steps = max_steps_env > 0 ? max_steps_env : 0x7fffffff;
     const uint32_t per_group = ((n + groups - 1) / groups + 2047U) / 2048U * 2048U;
@@ -509,7 +510,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         return PT_OK;
     };
 
-    const int check_every = n <= 65536 ? 4 : 16;
+    const int check_every = n <= 65536 ? 4 : env_int("PT_CHECK_EVERY", 8);
     uint64_t iterations = 0;
     int pending = 0;
     for(;;) {
@@ -555,7 +556,14 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         for(size_t g = 0; g < G.size(); g++) {
             if(!G[g].done) {
                 PT_HIP(hipStreamSynchronize(G[g].st));
-                G[g].done = s->host_counters[g].streams_done >= G[g].count;
+                const unsigned long long finished = s->host_counters[g].streams_done;
+                G[g].done = finished >= G[g].count;
+                // Endgame: once most streams have rendered all their pixels the launches are small, and suspending the long walks
+                // of the remaining streams only multiplies the number of (fixed-cost) iterations they need.
+                if(finished * 100ULL >= static_cast<unsigned long long>(G[g].count) * static_cast<unsigned long long>(endgame_percent)) {
+                    G[g].cfg.max_steps = 0x7fffffff;
+                    G[g].cfg.drain_lanes = 0;
+                }
             }
             all_done = all_done && G[g].done;
         }

@@ -295,7 +295,7 @@ int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot, uint32_t g
     PT_HIP(s->q_header.ensure(static_cast<size_t>(PT_MAX_GROUPS) * 2 * PT_SHARDS * PT_QSTRIDE));
     PT_HIP(s->counters.ensure(PT_MAX_GROUPS));
     PT_HIP(s->shade_wave_counters.ensure(2 * (static_cast<size_t>(n) / 64 + PT_MAX_GROUPS)));
-    PT_HIP(s->trace_wave_counters.ensure(static_cast<size_t>(s->trace_cfg.grid) * 4 * 4 * groups));
+    PT_HIP(s->trace_wave_counters.ensure(static_cast<size_t>(s->trace_cfg.grid) * 4 * 8 * groups));
     PT_HIP(s->spill.ensure(static_cast<size_t>(s->trace_cfg.grid) * 256 * s->trace_cfg.spill_depth * groups));
     {
         // room for a quarter of a group's rays to be suspended at once (a full pool only means walks are not suspended)
@@ -464,7 +464,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         const uint64_t blocks = (static_cast<uint64_t>(gr.count) * rays_per_slot + 255) / 256;
         gr.cfg.grid = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(gr.cfg.grid), blocks)));
         gr.cfg.spill = s->spill.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 256 * s->trace_cfg.spill_depth;
-        gr.cfg.wave_counters = s->trace_wave_counters.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 16;
+        gr.cfg.wave_counters = s->trace_wave_counters.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 32;
         gr.st = s->group_stream[n_groups];
         gr.done = false;
         n_groups++;
@@ -599,11 +599,20 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
                 c.samples += shade_slots[i];
                 c.vertices += shade_slots[i + 1];
             }
-            for(size_t i = 0; i + 3 < trace_slots.size(); i += 4) {
+            unsigned long long diag[4] = {0, 0, 0, 0};
+            for(size_t i = 0; i + 7 < trace_slots.size(); i += 8) {
                 c.node_visits += trace_slots[i];
                 c.leaf_tests += trace_slots[i + 1];
                 c.rays += trace_slots[i + 2];
                 c.shadow_rays += trace_slots[i + 3];
+                for(int k = 0; k < 4; k++) {
+                    diag[k] += trace_slots[i + 4 + k];
+                }
+            }
+            if(env_int("PT_DEBUG", 0) != 0) {
+                std::fprintf(stderr, "[pt] trace diagnostics: wave steps %llu (%.1f lanes of 64 on an inner node per step), leaf phases %llu (%.1f leaves each), refills %llu, suspended walks %llu\n",
+                             diag[0], diag[0] ? static_cast<double>(c.node_visits) / static_cast<double>(diag[0]) : 0.0, diag[1],
+                             diag[1] ? static_cast<double>(c.leaf_tests) / static_cast<double>(diag[1]) : 0.0, diag[2], diag[3]);
             }
         }
         stats->samples = c.samples;

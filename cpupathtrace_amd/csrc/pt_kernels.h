@@ -84,7 +84,7 @@ struct PtTraceConfig {
     int chunk;            // rays a wavefront reserves per dequeue atomic
     int burst_steps;      // inner-node steps between two looks at the leaves / the queue
     int drain_lanes;      // with the queue empty, a wavefront with at most this many walks left suspends them (0: never)
-    unsigned long long *wave_counters; // [grid * 4 waves][4] node visits, leaf tests, rays, shadow rays (plain adds, one slot per wave)
+    unsigned long long *wave_counters; // [grid * 4 waves][8] node visits, leaf tests, rays, shadow rays, wave steps, leaf phases, refills, suspended walks
 };
 
 void pt_launch_init_tiles(hipStream_t stream, PtPaths paths, const int4 *tiles, const uint32_t *tile_offset, uint32_t n_tiles, uint64_t base_seed);

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     uint32_t cur = PT_REF_NONE;
     int sp = 0;
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0;
-    uint32_t walk_start = 0; // n_nodes when the current walk began (diagnostic histogram of walk lengths)
+    uint32_t walk_start = 0; // n_nodes when the current walk began
+    uint32_t w_steps = 0, w_leaf_phases = 0, w_refills = 0, w_suspended = 0; // wave-level diagnostics (same value in every lane)
 
     for(;;) {
         // ---- 1. retire finished walks ----------------------------------------------------------------------------------
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                     }
                 }
             }
+            w_refills++;
             const uint32_t avail = res_end - res_next;
             const uint32_t first = res_next;
             res_next += avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             if(__ballot(on_inner) == 0ULL) {
                 break;
             }
+            w_steps++;
             if(on_inner) {
                 float4 q0, q1, q2, q3;
                 if(LDS_MODE == 2 || (LDS_MODE == 1 && cur < sc.n_lds_pairs)) {
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             const bool over = active && cur != PT_REF_NONE && (steps_here >= (uint32_t)max_steps || (few_left && steps_here >= 32u));
             const unsigned long long over_mask = __ballot(over);
             if(over_mask != 0ULL) {
+                w_suspended += (uint32_t)__popcll(over_mask);
                 uint32_t base = 0;
                 if(lane == 0) {
                     base = atomicAdd(&carry.count[carry_out * PT_QSTRIDE], (uint32_t)__popcll(over_mask));
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
         const bool on_leaf = active && (cur & PT_REF_LEAF) && cur != PT_REF_NONE;
         const unsigned long long leaf_mask = __ballot(on_leaf);
         if(leaf_mask != 0ULL && (__popcll(leaf_mask) >= leaf_min || __ballot(active && !(cur & PT_REF_LEAF)) == 0ULL)) {
+            w_leaf_phases++;
             if(on_leaf) {
                 const uint32_t idx = cur & PT_REF_INDEX;
                 float t;
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     }
 
     if(COUNT) {
-        // Work counters: every wave owns one 32-byte slot and adds its totals with plain stores.  (Atomics on one shared line
+        // Work counters: every wave owns one 64-byte slot and adds its totals with plain stores.  (Atomics on one shared line
         // from every wave of the grid serialise at the memory side -- about 40 ns each -- and were a visible part of the launch.)
         for(int off = 32; off > 0; off >>= 1) {
             n_nodes += __shfl_down(n_nodes, off);
@@ -449,11 +454,15 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
             n_shadow += __shfl_down(n_shadow, off);
         }
         if(lane == 0) {
-            unsigned long long *slot = wave_counters + 4 * ((size_t)blockIdx.x * 4 + (tid >> 6));
+            unsigned long long *slot = wave_counters + 8 * ((size_t)blockIdx.x * 4 + (tid >> 6));
             slot[0] += n_nodes;
             slot[1] += n_leaves;
             slot[2] += n_rays;
             slot[3] += n_shadow;
+            slot[4] += w_steps;
+            slot[5] += w_leaf_phases;
+            slot[6] += w_refills;
+            slot[7] += w_suspended;
         }
     }
 }

@@ -69,6 +69,22 @@ def ref_formula_bytes_per_sample(R, A, T, V):
     return R * (A * 32.0 + T * 36.0 + 96.0) + V * 100.0 + 16.0
 
 
+def measured_traffic(workload_key, launches_scale=1.0):
+    """HBM bytes per launch of the dominant kernel from the newest profiles/r*_traffic.json (written by tools/measure_traffic.py
+    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same workload, with the gfx950 correction of
+    MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request, calibrated on tools/gather_bench.hip).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    for path in reversed(files):
+        try:
+            entry = json.load(open(path)).get(workload_key)
+        except (OSError, ValueError):
+            continue
+        if entry:
+            return entry.get("bytes_per_launch"), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(sc, cam, opt, seconds_target):
     """The reference itself (oracle/_ref, kind "reference") or, if that was not built, the C restatement (kind "port"),
     timed on this host's cores on a bounded random subset of the SAME frame's pixels (same scene, same spp)."""
@@ -189,7 +205,9 @@ def main():
         launches = max(s["iterations"], 1)
         trace_s = s["trace_ms"] / 1e3
         achieved = bytes_per_sample * samples / max(trace_s, 1e-9) / 1e9
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        traffic, traffic_source = measured_traffic("%s-%d" % (args.workload, args.mesh_n if args.workload.startswith("dragon") else 0))
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_per_sample * samples / launches,
                     "kernel": "pt_trace_kernel", "avg_launch_ms": s["trace_ms"] / launches, "launches_per_step": launches,
                     "algorithmic_bytes_per_sample": bytes_per_sample,
                     "per_sample": {"rays": R, "aabb_tests_per_ray": A, "leaf_tests_per_ray": T, "vertices": V},

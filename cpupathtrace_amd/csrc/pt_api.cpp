@@ -143,7 +143,7 @@ struct pt_scene {
     std::vector<float> emissive_cdf;
 
     // device scene
-    DevBuf<F4> pairs, tris, tri_nrm, spheres, materials, lights, emis;
+    DevBuf<F4> pairs, tris, tri_shade, spheres, materials, lights, emis;
     DevBuf<uint2> sph_meta;
     DevBuf<float> emis_cdf;
     PtDevScene dev{};
@@ -228,7 +228,7 @@ PtPaths make_paths(pt_scene *s, uint32_t n, uint32_t start = 0) {
     P.est = s->est.ptr + start;
     P.cand = s->cand.ptr + static_cast<size_t>(start) * PT_MAX_CANDIDATES;
     P.hit = s->hit.ptr + start;
-    P.vis = s->vis.ptr + static_cast<size_t>(start) * PT_MAX_NEE;
+    P.vis = s->vis.ptr + start;
     P.wave_counters = s->shade_wave_counters.ptr + 2 * static_cast<size_t>(start / 64);
     return P;
 }
@@ -774,7 +774,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     ptb::FlatBvh flat = ptb::flatten_breadth_first(s->tree, leaf_ref, env_int("PT_ALIGN_SIBLINGS", 1) != 0);
 
     // ---- triangle / sphere / material records --------------------------------------------------------------------------------
-    std::vector<F4> tris(3 * static_cast<size_t>(d->n_triangles)), nrm(3 * static_cast<size_t>(d->n_triangles));
+    std::vector<F4> tris(3 * static_cast<size_t>(d->n_triangles)), shade(8 * static_cast<size_t>(d->n_triangles), F4{0.0F, 0.0F, 0.0F, 0.0F});
     for(uint32_t t = 0; t < d->n_triangles; t++) {
         const float *p = d->tri_pos + 9 * static_cast<size_t>(t);
         const Vec3 a = ld(p), b = ld(p + 3), c = ld(p + 6);
@@ -793,9 +793,12 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         else {
             na = nb = nc = normalize(cross(ab, ac)); // Triangle::Triangle, object.cpp:118-124
         }
-        nrm[3 * static_cast<size_t>(t) + 0] = {na.x, na.y, na.z, nb.x};
-        nrm[3 * static_cast<size_t>(t) + 1] = {nb.y, nb.z, nc.x, nc.y};
-        nrm[3 * static_cast<size_t>(t) + 2] = {nc.z, 0.0F, 0.0F, 0.0F};
+        for(int k = 0; k < 3; k++) {
+            shade[8 * static_cast<size_t>(t) + k] = tris[3 * static_cast<size_t>(t) + k];
+        }
+        shade[8 * static_cast<size_t>(t) + 3] = {na.x, na.y, na.z, nb.x};
+        shade[8 * static_cast<size_t>(t) + 4] = {nb.y, nb.z, nc.x, nc.y};
+        shade[8 * static_cast<size_t>(t) + 5] = {nc.z, 0.0F, 0.0F, 0.0F};
     }
     std::vector<F4> spheres(d->n_spheres);
     std::vector<uint2> sph_meta(d->n_spheres);
@@ -896,7 +899,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     std::memcpy(pairs.data(), flat.pairs.data(), flat.pairs.size() * sizeof(float));
     PT_HIP(s->pairs.upload(pairs));
     PT_HIP(s->tris.upload(tris));
-    PT_HIP(s->tri_nrm.upload(nrm));
+    PT_HIP(s->tri_shade.upload(shade));
     PT_HIP(s->spheres.upload(spheres));
     PT_HIP(s->sph_meta.upload(sph_meta));
     PT_HIP(s->materials.upload(materials));
@@ -907,7 +910,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     PtDevScene &dev = s->dev;
     dev.pairs = reinterpret_cast<const float4 *>(s->pairs.ptr);
     dev.tris = reinterpret_cast<const float4 *>(s->tris.ptr);
-    dev.tri_nrm = reinterpret_cast<const float4 *>(s->tri_nrm.ptr);
+    dev.tri_shade = reinterpret_cast<const float4 *>(s->tri_shade.ptr);
     dev.spheres = reinterpret_cast<const float4 *>(s->spheres.ptr);
     dev.sph_meta = s->sph_meta.ptr;
     dev.materials = reinterpret_cast<const float4 *>(s->materials.ptr);
@@ -1094,7 +1097,7 @@ int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_opti
     if(n == 0) {
         return PT_OK;
     }
-    if(n > 0x3fffffffULL) {
+    if(n > 0x0fffffffULL) {
         return fail(PT_ERR_INVALID, "too many streams");
     }
     PtDevOptions opt;
@@ -1160,7 +1163,7 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
         offsets[i] = static_cast<uint32_t>(total);
         total += static_cast<uint64_t>(t.w) * static_cast<uint64_t>(t.h);
     }
-    if(total > 0x3fffffffULL) {
+    if(total > 0x0fffffffULL) {
         return fail(PT_ERR_INVALID, "too many pixels in one call");
     }
     const uint32_t n32 = static_cast<uint32_t>(total);

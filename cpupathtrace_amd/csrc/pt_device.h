@@ -471,9 +471,9 @@ PT_D V3 object_normal(const PtDevScene &sc, uint32_t ref, V3 pos, uint32_t &mate
         material = sc.sph_meta[idx].x;
         return normalize(pos - v3(s.x, s.y, s.z)); // object.cpp:86-88
     }
-    TriRec t = tri_load(sc.tris, idx);
-    const float4 *np = sc.tri_nrm + 3 * (size_t)idx;
-    float4 n0 = np[0], n1 = np[1], n2 = np[2];
+    const float4 *rec = sc.tri_shade + 8 * (size_t)idx; // one 128-byte line: geometry words, then the vertex normals
+    const TriRec t = tri_unpack(rec[0], rec[1], rec[2]);
+    const float4 n0 = rec[3], n1 = rec[4], n2 = rec[5];
     material = t.material;
     return tri_normal(t.a, t.ab, t.ac, v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), v3(n1.z, n1.w, n2.x), pos);
 }

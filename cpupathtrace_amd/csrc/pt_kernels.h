@@ -31,7 +31,7 @@ struct PtPaths {
     PtCandidate *cand;     // [n][PT_MAX_CANDIDATES]
     // results of the traversal kernel
     uint2 *hit;            // [n] (bits t, ref) of the extension ray
-    uint32_t *vis;         // [n][PT_MAX_NEE] 1 = shadow ray unoccluded
+    uint32_t *vis;         // [PT_MAX_NEE][nee_stride] 1 = shadow ray unoccluded, 0 = occluded, PT_VIS_PENDING = still walking
     unsigned long long *wave_counters; // [ceil(n / 64)][2] samples finished, vertices shaded (plain adds, one slot per wave)
 };
 
@@ -40,12 +40,13 @@ struct PtPaths {
 #define PT_F_HAS_EXT 4u   /* an extension (camera/bounce) ray was traced for it */
 #define PT_F_COLLECTED 8u /* sample_collected (worker.cpp:37) */
 #define PT_F_PIXEL 16u    /* the estimator of the current pixel is initialised */
+#define PT_F_SAFE 64u     /* the estimator cannot stop at the sample in flight and another sample of the pixel follows (see pt_shade.hip) */
 #define PT_F_OVERLAP 32u  /* the next sample's camera ray is already in flight while the previous sample waits for its last shadow rays */
 
 // Ray queue: PT_SHARDS append-only segments of `shard_capacity` rays each.
 struct PtQueue {
     float4 *ray_o;   // origin xyz, w = shadow threshold |to_light| - epsilon (worker.cpp:86) or unused
-    float4 *ray_d;   // direction xyz, w = bits destination: bit 31 = shadow ray, low bits = slot (ext) or slot * PT_MAX_NEE + j
+    float4 *ray_d;   // direction xyz, w = bits destination: bit 31 = shadow ray, low bits = slot (ext) or j * nee_stride + slot
     uint32_t *count; // [PT_SHARDS * PT_QSTRIDE] rays appended to shard s at count[s * PT_QSTRIDE]
     uint32_t *head;  // [PT_SHARDS * PT_QSTRIDE] rays dequeued from shard s at head[s * PT_QSTRIDE]
     uint32_t shard_capacity;

@@ -192,6 +192,16 @@ PT_D C4 estimator_finish(PtEstimator &e, PtCandidate *cand, const PtDevOptions &
     return pixel_value;
 }
 
+// Can the sample AFTER the one that is about to start begin before that one is handed to the estimator?  Only if another sample
+// of the same pixel certainly follows it: it is not the last one (worker.cpp:193) and the convergence test cannot run at it --
+// the test runs only when a COLLECTED sample closes a statistics batch with at least max(min_sample_count, 2) samples collected
+// (worker.cpp:239).  `e` is the estimator state before the sample; the question is only asked for samples that reach a vertex.
+PT_D bool estimator_safe_to_overlap(const PtEstimator &e, const PtDevOptions &opt) {
+    const bool closes_batch = e.stats_sample_index + 1 == opt.stats_sample_count;
+    const int min_needed = opt.min_sample_count > 2 ? opt.min_sample_count : 2;
+    return e.pixel_sample + 1 < opt.max_sample_count && !(closes_batch && e.collected_sample_count + 1 >= min_needed);
+}
+
 PT_D void estimator_reset(PtEstimator &e, const PtDevOptions &opt) {
     for(int k = 0; k < 4; k++) {
         e.pixel_value[k] = 0.0f;
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScen
         bool ready = !(flags & PT_F_HAS_EXT) || P.hit[p].y != PT_REF_PENDING;
         uint32_t mask = P.nee_mask[p];
         for(uint32_t j = 0; mask != 0; j++, mask >>= 1) {
-            if((mask & 1u) && P.vis[(size_t)p * PT_MAX_NEE + j] == PT_VIS_PENDING) {
+            if((mask & 1u) && P.vis[(size_t)j * P.nee_stride + p] == PT_VIS_PENDING) {
                 ready = false;
             }
         }
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScen
             // shadow rays of the previous vertex, in light order (worker.cpp:76-103)
             uint32_t mask = P.nee_mask[p];
             for(uint32_t j = 0; mask != 0; j++, mask >>= 1) {
-                if((mask & 1u) && P.vis[(size_t)p * PT_MAX_NEE + j] != 0u) {
+                if((mask & 1u) && P.vis[(size_t)j * P.nee_stride + p] != 0u) {
                     out = out + c4(P.nee[(size_t)j * P.nee_stride + p]);
                 }
             }
@@ -360,7 +370,10 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScen
                 e.pixel_sample++;
                 n_samples++;
                 P.est[p] = e;
-                flags &= ~(PT_F_OVERLAP | PT_F_COLLECTED);
+                flags &= ~(PT_F_OVERLAP | PT_F_COLLECTED | PT_F_SAFE);
+                if(estimator_safe_to_overlap(e, opt)) {
+                    flags |= PT_F_SAFE;
+                }
                 out = c4(0, 0, 0, 0);
             }
             bool finished = true;
@@ -395,7 +408,10 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScen
                     flags &= ~PT_F_PIXEL;
                 }
                 P.est[p] = e;
-                flags &= ~(PT_F_IN_FLIGHT | PT_F_HAS_EXT | PT_F_COLLECTED);
+                flags &= ~(PT_F_IN_FLIGHT | PT_F_HAS_EXT | PT_F_COLLECTED | PT_F_SAFE);
+                if((flags & PT_F_PIXEL) && estimator_safe_to_overlap(e, opt)) {
+                    flags |= PT_F_SAFE; // for the pixel's next sample, which starts below
+                }
                 start_sample = true;
             }
             else {
@@ -437,7 +453,10 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScen
                 PtEstimator e;
                 estimator_reset(e, opt);
                 P.est[p] = e;
-                flags |= PT_F_PIXEL;
+                flags = (flags | PT_F_PIXEL) & ~PT_F_SAFE;
+                if(estimator_safe_to_overlap(e, opt)) {
+                    flags |= PT_F_SAFE;
+                }
                 if(opt.max_sample_count <= 0) {
                     // no sample at all: the pixel stays (0, 0, 0, 0) (worker.cpp:193,263-265)
                     const int32_t px = rc.x + cur % rc.z, py = rc.y + cur / rc.z;
@@ -492,16 +511,7 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScen
         // BSDF::getSpectrum(..., synthetic = true) returns p = 0 for glass and mirror: their light samples never
         // contribute (worker.cpp:92), so no shadow ray is needed -- the light-sampling draws are still consumed below.
         want_nee = mat.bsdf == 0 && n_light_samples > 0;
-        // Can the next sample start before this one is handed to the estimator?  Only if another sample of the same pixel
-        // certainly follows: this is not the last one (worker.cpp:193) and the convergence test cannot run at it -- the test
-        // runs only when this sample closes a statistics batch with at least max(min_sample_count, 2) samples collected
-        // (worker.cpp:239).
-        {
-            const PtEstimator *e = P.est + p;
-            const bool closes_batch = e->stats_sample_index + 1 == opt.stats_sample_count;
-            const int min_needed = opt.min_sample_count > 2 ? opt.min_sample_count : 2;
-            safe_overlap = e->pixel_sample + 1 < opt.max_sample_count && !(closes_batch && e->collected_sample_count + 1 >= min_needed);
-        }
+        safe_overlap = (flags & PT_F_SAFE) != 0; // decided when the sample started (estimator_safe_to_overlap)
         // an extension ray: the bounce (may still be cancelled by the 1E-20 guards, worker.cpp:112,134) or the next sample's camera ray
         emit_ext = do_bounce || safe_overlap;
     }
@@ -568,15 +578,15 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScen
                         const float threshold = len(to_light) - epsilon;
                         if(threshold <= 0.0f) {
                             // light_t < 0 || light_t >= threshold holds for every light_t
-                            P.vis[(size_t)p * PT_MAX_NEE + j] = 1u;
+                            P.vis[(size_t)j * P.nee_stride + p] = 1u;
                         }
                         else {
                             need_ray = true;
-                            P.vis[(size_t)p * PT_MAX_NEE + j] = PT_VIS_PENDING;
+                            P.vis[(size_t)j * P.nee_stride + p] = PT_VIS_PENDING;
                             const V3 so = pos + light_dir * epsilon;
                             q.ray_o[nee_slot + j] = make_float4(so.x, so.y, so.z, threshold);
                             q.ray_d[nee_slot + j] =
-                              make_float4(light_dir.x, light_dir.y, light_dir.z, __uint_as_float(PT_DEST_SHADOW | (p * PT_MAX_NEE + j)));
+                              make_float4(light_dir.x, light_dir.y, light_dir.z, __uint_as_float(PT_DEST_SHADOW | (j * P.nee_stride + p)));
                         }
                     }
                 }

@@ -12,7 +12,8 @@
 //                                     q0 = (a.x, a.y, a.z, ab.x)  q1 = (ab.y, ab.z, ac.x, ac.y)  q2 = (ac.z, bits material, bits (obj | cull << 31), 0)
 //                                   ab = b - a and ac = c - a are the fp32 differences the reference forms on every call
 //                                   (src/scene/object.cpp:127-128,149-150), formed once on the host.
-//   tri_nrm   float4[3 * n_tris]    vertex normals: (na.xyz, nb.x) (nb.yz, nc.xy) (nc.z, 0, 0, 0)
+//   tri_shade float4[8 * n_tris]    128-byte (one HBM line) record per triangle for the shading kernel: the three words of `tris`
+//                                   followed by the vertex normals (na.xyz, nb.x) (nb.yz, nc.xy) (nc.z, 0, 0, 0) and padding
 //   spheres   float4[n_spheres]     (origin.xyz, radius);  sph_meta uint2[n_spheres] = (material, obj)
 //   materials float4[4 * n_mat]     diffuse, specular, emission, (ior, bits bsdf, bits one_way, 0)
 //   lights    float4[2 * n_lights]  (pos.xyz, 0), spectrum rgba
@@ -42,7 +43,7 @@
 struct PtDevScene {
     const float4 *pairs;
     const float4 *tris;
-    const float4 *tri_nrm;
+    const float4 *tri_shade;
     const float4 *spheres;
     const uint2 *sph_meta;
     const float4 *materials;

@@ -33,6 +33,27 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class heartbeat:
+    """Prints a line to stderr every 45 s while a long host phase (mesh generation, BVH build) runs."""
+
+    def __init__(self, what):
+        import threading
+        self.what, self.stop, self.t0 = what, threading.Event(), time.time()
+        self.thread = threading.Thread(target=self.run, daemon=True)
+
+    def run(self):
+        while not self.stop.wait(45.0):
+            log("... %s (%.0f s)" % (self.what, time.time() - self.t0))
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.thread.join()
+
+
 def frame_for(n_gpus, base):
     a = 1
     while a * a < n_gpus:
@@ -158,10 +179,12 @@ def main():
     from cpupathtrace_amd import binding, scenes, sharding
 
     width, height = frame_for(n_gpus, args.size)
-    sc, cam, label, gen_s = build_workload(args.workload, width, height, args.mesh_n)
+    with heartbeat("generating the scene"):
+        sc, cam, label, gen_s = build_workload(args.workload, width, height, args.mesh_n)
     opt = scenes.options(width, height, args.spp, args.spp)
     t0 = time.time()
-    scene = binding.Scene(sc, device=local_rank)
+    with heartbeat("building the BVH and uploading the scene"):
+        scene = binding.Scene(sc, device=local_rank)
     create_s = time.time() - t0
     info = scene.info()
     if rank == 0:

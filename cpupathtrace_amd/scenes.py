@@ -250,19 +250,21 @@ def dragon_box_scene(mesh_pos, mesh_nrm, aspect_ratio=-1.0, copies=1):
 
 def dragon_grid_scene(mesh_pos, mesh_nrm, aspect_ratio=-1.0, grid=4):
     """BASELINE.json configs[4]: grid x grid transformed COPIES of the mesh (the reference has no instancing: every copy is its
-    own set of Triangle objects) on the floor of an enlarged box, same light and camera layout as DragonBox."""
+    own set of Triangle objects), one per unit cell of a wall of cells in the x-y plane, inside DragonBox
+    (benchmark/main.cpp:59-105) widened `grid` times in x and y.  Camera, light quad and viewing distance are DragonBox's scaled
+    the same way, so the box fills the frame exactly as it does there."""
     sb = SceneBuilder()
-    half = F(grid)  # box half-extent: one unit cell per copy
-    sb.triangles(make_box((-half, -1.0, -half), (half, 1.0, half)))
+    half = F(grid)  # box half-extent in x and y: one 2 x 2 cell per copy
+    sb.triangles(make_box((-half, -half, -1.0), (half, half, 1.0)))
     light = sb.material((1, 1, 1, 1), 1.0, (1, 1, 1, 1))
-    sb.triangles(make_plane((-0.25 * grid, F(1.0) - F(0.01), -0.25 * grid), (0.25 * grid, F(1.0) - F(0.01), 0.25 * grid)), light, cull=True)
+    sb.triangles(make_plane((-0.25 * grid, half - F(0.01), -0.25), (0.25 * grid, half - F(0.01), 0.25)), light, cull=True)
     glass = sb.material((1, 1, 1, 1), 1.5, bsdf=BSDF_GLASS)
     pos = np.asarray(mesh_pos, dtype=F).reshape(-1, 3, 3)
-    for gz in range(grid):
+    for gy in range(grid):
         for gx in range(grid):
-            shift = np.array([F(2 * gx + 1) - half, 0, F(2 * gz + 1) - half], dtype=F)
+            shift = np.array([F(2 * gx + 1) - half, F(2 * gy + 1) - half, 0], dtype=F)
             sb.triangles(pos + shift, glass, cull=False, normals=mesh_nrm)
-    cam = camera((0, 0.5, -3.0 * grid), (0, -0.3, 0), (0, 1, 0), 1.0, 1.0, aspect_ratio)
+    cam = camera((0, 0, -1.0 - 2.0 * grid), (0, 0, 0), (0, 1, 0), 1.0, 1.0, aspect_ratio)
     return sb.build(), cam
 
 

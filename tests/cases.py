@@ -45,6 +45,8 @@ def scene_set(mesh):
     simple, simple_cam = scenes.simple_scene()
     dbox, dbox_cam = scenes.dragon_box_scene(mpos, mnrm)
     cmesh, cmesh_cam = scenes.cornell_scene(256, 256, *demo_mesh(mesh))
+    # BASELINE.json configs[4] at test size: 16 copies of a 448-triangle mesh (the bench uses 7.2 M triangles per copy)
+    d16, d16_cam = scenes.dragon_grid_scene(*scenes.bumpy_sphere_mesh(16, 16, scenes.DRAGON_BOX_TRANSFORM), grid=4)
     return {
         "box": (box, box_cam),
         "cornell": (cornell, cornell_cam),
@@ -52,6 +54,7 @@ def scene_set(mesh):
         "simple": (simple, simple_cam),
         "meshbox": (dbox, dbox_cam),
         "cornellmesh": (cmesh, cmesh_cam),
+        "dragons16": (d16, d16_cam),
     }
 
 

@@ -102,7 +102,7 @@ def test_tiles_one_engine(gpu_scenes, sset):
     assert_bits_equal(st, g["advanced_edge_state"], "edge tile state")
 
 
-@pytest.mark.parametrize("name,w,h,mn,mx", [("box", 64, 64, 16, 64), ("cornell", 48, 40, 16, 16), ("advanced", 66, 34, 5, 10), ("meshbox", 32, 32, 8, 8)])
+@pytest.mark.parametrize("name,w,h,mn,mx", [("box", 64, 64, 16, 64), ("cornell", 48, 40, 16, 16), ("advanced", 66, 34, 5, 10), ("meshbox", 32, 32, 8, 8), ("dragons16", 48, 48, 8, 8)])
 def test_process_job_vs_oracle(gpu_scenes, sset, oracle_lib, name, w, h, mn, mx):
     """processJob with per-pixel engines against the CPU oracle run on the same engines.  Stated tolerance: per-pixel
     L2 error < 1e-4 (BASELINE.json north_star); the implementation is expected to be bit-identical."""

@@ -67,12 +67,13 @@ def test_bsdf_fresh_inputs(ref_lib, oracle_lib, kind, one_way):
         assert_bits_equal(a, b, "propagateRay (powf, sinf, cosf)")
 
 
-@pytest.mark.parametrize("name", ["box", "cornell", "advanced", "meshbox"])
+@pytest.mark.parametrize("name", ["box", "cornell", "advanced", "meshbox", "dragons16"])
 def test_scene_fresh_inputs(ref_lib, oracle_lib, name):
     sc, cam = scene_set(golden_mesh())[name]
     rng = np.random.default_rng(303)
     n = 50000
-    rays = np.concatenate([rng.uniform(-0.9, 0.9, (n, 3)), _unit(rng.normal(size=(n, 3)))], axis=1).astype(F)
+    extent = np.array([3.9, 3.9, 0.9] if name == "dragons16" else [0.9, 0.9, 0.9])
+    rays = np.concatenate([rng.uniform(-1, 1, (n, 3)) * extent, _unit(rng.normal(size=(n, 3)))], axis=1).astype(F)
     ho, hr = oracle_lib.scene_create(sc), ref_lib.scene_create(sc)
     (to, oo), (tr, orr) = ho.intersect(rays), hr.intersect(rays)
     miss_equal(to, tr, "closest hit")

@@ -176,6 +176,14 @@ class Scene:
         _check(load().pt_scene_info(self._h, C.byref(n), C.byref(depth), C.byref(ne)))
         return {"n_nodes": n.value, "depth": depth.value, "n_emissive": ne.value}
 
+    def emissive(self):
+        """Emissive objects in Scene::registerEmissiveObjects order (scene.cpp:183-208) and their normalised CDF."""
+        n = self.info()["n_emissive"]
+        obj, cdf = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.float32)
+        written = C.c_uint64()
+        _check(load().pt_scene_emissive(self._h, _ptr(obj), _ptr(cdf), C.c_uint64(n), C.byref(written)))
+        return obj[:n], cdf[:n]
+
     def bvh_dump(self):
         n = max(2 * self.n_objects - 1, 1)
         obj, box = np.empty(n, np.int32), np.empty((n, 6), np.float32)

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 #include <thread>
 #include <vector>
 
+#include "pt_build.h"
 #include "pt_bvh.h"
 #include "pt_kernels.h"
 
@@ -134,7 +136,11 @@ struct pt_scene {
     int cu_count = 256;
 
     // host copies kept for introspection and for mapping references back to object indices
-    ptb::Tree tree;
+    ptb::Tree tree;          // host-built scenes only (PT_BUILD=host or few objects); empty when the device built the tree
+    uint64_t n_nodes = 0;    // 2 * n_objects - 1
+    uint32_t depth = 0;      // levels of the tree (a single leaf has depth 1)
+    bool device_built = false;
+    float build_ms[4] = {0, 0, 0, 0}; // host preparation, upload, device tree construction, emissive registration + rest
     std::vector<uint32_t> tri_obj;
     std::vector<uint32_t> sph_obj;
     uint32_t n_objects = 0;
@@ -251,7 +257,7 @@ PtCarry make_carry(pt_scene *s, uint32_t group = 0) {
     c.ray_d = reinterpret_cast<float4 *>(s->carry_d.ptr) + base;
     c.state = s->carry_state.ptr + base;
     c.sp = s->carry_sp.ptr + base;
-    c.depth = std::max<uint32_t>(s->tree.depth, 1U);
+    c.depth = std::max<uint32_t>(s->depth, 1U);
     c.stack = s->carry_stack.ptr + base * c.depth;
     c.count = s->carry_header.ptr + static_cast<size_t>(group) * 4 * PT_QSTRIDE;
     c.head = c.count + 2 * PT_QSTRIDE;
@@ -307,7 +313,7 @@ int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot, uint32_t g
             PT_HIP(s->carry_d.ensure(total));
             PT_HIP(s->carry_state.ensure(total));
             PT_HIP(s->carry_sp.ensure(total));
-            PT_HIP(s->carry_stack.ensure(total * std::max<uint32_t>(s->tree.depth, 1U)));
+            PT_HIP(s->carry_stack.ensure(total * std::max<uint32_t>(s->depth, 1U)));
         }
         PT_HIP(s->carry_header.ensure(static_cast<size_t>(PT_MAX_GROUPS) * 4 * PT_QSTRIDE));
     }
@@ -343,7 +349,7 @@ int setup_trace(pt_scene *s) {
     const int per_cu = pt_trace_blocks_per_cu(stack_lds, cfg.lds_mode, cfg.lds_bytes);
     const int limit = env_int("PT_TRACE_BLOCKS_PER_CU", 0);
     cfg.grid = s->cu_count * ((limit > 0 && limit < per_cu) ? limit : per_cu);
-    cfg.spill_depth = s->tree.depth > static_cast<uint32_t>(stack_lds) ? s->tree.depth - static_cast<uint32_t>(stack_lds) : 1U;
+    cfg.spill_depth = s->depth > static_cast<uint32_t>(stack_lds) ? s->depth - static_cast<uint32_t>(stack_lds) : 1U;
     cfg.spill = nullptr; // allocated with the workspace (one area per group)
     // measured (profiles/): short LDS-resident walks want few dequeue atomics (256 rays each, refill at 20 idle lanes); long walks
     // through HBM-resident trees want fine-grained balancing between wavefronts (96 rays, refill at 12)
@@ -717,23 +723,20 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     PT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     s->n_objects = d->n_objects;
 
-    // ---- leaves: bounding volume and reference word per object, in construction order --------------------------------
-    std::vector<ptb::Box> boxes(d->n_objects);
+    using clock = std::chrono::steady_clock;
+    const auto t_begin = clock::now();
+    auto ms_since = [](clock::time_point t0) { return std::chrono::duration<float, std::milli>(clock::now() - t0).count(); };
+
+    // ---- objects in construction order: typed indices and the reference word of every leaf ---------------------------------
     std::vector<uint32_t> leaf_ref(d->n_objects);
     s->tri_obj.resize(d->n_triangles);
     s->sph_obj.resize(d->n_spheres);
     {
         uint32_t ti = 0, si = 0;
         for(uint32_t i = 0; i < d->n_objects; i++) {
-            ptb::Box &b = boxes[i];
             if(d->obj_kind[i] == PT_OBJ_TRIANGLE) {
                 if(ti >= d->n_triangles) {
                     return fail(PT_ERR_INVALID, "obj_kind lists more triangles than n_triangles");
-                }
-                const float *p = d->tri_pos + 9 * static_cast<size_t>(ti);
-                for(int k = 0; k < 3; k++) { // Triangle::getBoundingVolume, object.cpp:184-186
-                    b.lo[k] = fmin_std(fmin_std(p[k], p[3 + k]), p[6 + k]);
-                    b.hi[k] = fmax_std(fmax_std(p[k], p[3 + k]), p[6 + k]);
                 }
                 leaf_ref[i] = PT_REF_LEAF | ti;
                 s->tri_obj[ti] = i;
@@ -745,11 +748,6 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
             else if(d->obj_kind[i] == PT_OBJ_SPHERE) {
                 if(si >= d->n_spheres) {
                     return fail(PT_ERR_INVALID, "obj_kind lists more spheres than n_spheres");
-                }
-                const float *sp = d->sph + 4 * static_cast<size_t>(si);
-                for(int k = 0; k < 3; k++) { // Sphere::getBoundingVolume, object.cpp:90-93
-                    b.lo[k] = sp[k] - sp[3];
-                    b.hi[k] = sp[k] + sp[3];
                 }
                 leaf_ref[i] = PT_REF_LEAF | PT_REF_SPHERE | si;
                 s->sph_obj[si] = i;
@@ -763,50 +761,210 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
             }
         }
     }
+    s->n_nodes = d->n_objects > 0 ? 2ULL * d->n_objects - 1ULL : 0ULL;
 
-    // ---- BVH -------------------------------------------------------------------------------------------------------------
-    int threads = env_int("PT_BUILD_THREADS", static_cast<int>(std::thread::hardware_concurrency()));
-    threads = std::max(1, std::min(threads, 64));
-    s->tree = ptb::build_reference_bvh(boxes, threads);
-    if(s->tree.depth > PT_MAX_DEPTH) {
-        return fail(PT_ERR_UNSUPPORTED, "BVH deeper than 128 levels");
+    // Where the tree is built.  PT_BUILD=device | host forces one; by default scenes of 1024 objects or more are built on the
+    // device (pt_build.hip) and smaller ones by the host recursion (pt_bvh.cpp).  Both produce the same arrays, bit for bit.
+    bool use_device = d->n_objects >= static_cast<uint32_t>(std::max(env_int("PT_BUILD_DEVICE_MIN", 1024), 2));
+    if(const char *mode = std::getenv("PT_BUILD")) {
+        if(std::strcmp(mode, "host") == 0) {
+            use_device = false;
+        }
+        else if(std::strcmp(mode, "device") == 0) {
+            use_device = d->n_objects >= 2;
+        }
     }
-    ptb::FlatBvh flat = ptb::flatten_breadth_first(s->tree, leaf_ref, env_int("PT_ALIGN_SIBLINGS", 1) != 0);
+    s->device_built = use_device;
+    const bool align_siblings = env_int("PT_ALIGN_SIBLINGS", 1) != 0;
 
-    // ---- triangle / sphere / material records --------------------------------------------------------------------------------
-    std::vector<F4> tris(3 * static_cast<size_t>(d->n_triangles)), shade(8 * static_cast<size_t>(d->n_triangles), F4{0.0F, 0.0F, 0.0F, 0.0F});
-    for(uint32_t t = 0; t < d->n_triangles; t++) {
-        const float *p = d->tri_pos + 9 * static_cast<size_t>(t);
-        const Vec3 a = ld(p), b = ld(p + 3), c = ld(p + 6);
-        const Vec3 ab = sub(b, a), ac = sub(c, a);
-        const uint32_t obj_cull = s->tri_obj[t] | (d->tri_cull[t] != 0 ? 0x80000000U : 0U);
-        tris[3 * static_cast<size_t>(t) + 0] = {a.x, a.y, a.z, ab.x};
-        tris[3 * static_cast<size_t>(t) + 1] = {ab.y, ab.z, ac.x, ac.y};
-        tris[3 * static_cast<size_t>(t) + 2] = {ac.z, from_bits(d->tri_material[t]), from_bits(obj_cull), 0.0F};
-        Vec3 na, nb, nc;
+    std::vector<int32_t> dfs; // leaves depth-first, left to right (Scene::registerEmissiveObjects order); device path: only those with an emissive material
+    uint32_t n_pairs = 0, root_ref = PT_REF_NONE;
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+    if(use_device) {
+        // ---- device: upload the caller's arrays as they are; records, leaf boxes and the tree are made in HBM ----------------------
+        s->build_ms[0] = ms_since(t_begin);
+        const auto t_upload = clock::now();
+        DevBuf<float> raw_pos, raw_nrm, raw_sph;
+        DevBuf<uint8_t> raw_cull;
+        DevBuf<uint32_t> raw_tri_mat, raw_tri_obj, raw_sph_mat, raw_sph_obj;
+        auto up = [](auto &buf, const auto *src, size_t count) -> hipError_t {
+            hipError_t e = buf.ensure(count);
+            if(e != hipSuccess || count == 0) {
+                return e;
+            }
+            return hipMemcpy(buf.ptr, src, count * sizeof(*src), hipMemcpyHostToDevice);
+        };
+        PT_HIP(up(raw_pos, d->tri_pos, 9 * static_cast<size_t>(d->n_triangles)));
         if(d->tri_nrm != nullptr) {
-            const float *q = d->tri_nrm + 9 * static_cast<size_t>(t);
-            na = ld(q);
-            nb = ld(q + 3);
-            nc = ld(q + 6);
+            PT_HIP(up(raw_nrm, d->tri_nrm, 9 * static_cast<size_t>(d->n_triangles)));
         }
-        else {
-            na = nb = nc = normalize(cross(ab, ac)); // Triangle::Triangle, object.cpp:118-124
+        PT_HIP(up(raw_cull, d->tri_cull, d->n_triangles));
+        PT_HIP(up(raw_tri_mat, d->tri_material, d->n_triangles));
+        PT_HIP(up(raw_tri_obj, s->tri_obj.data(), d->n_triangles));
+        PT_HIP(up(raw_sph, d->sph, 4 * static_cast<size_t>(d->n_spheres)));
+        PT_HIP(up(raw_sph_mat, d->sph_material, d->n_spheres));
+        PT_HIP(up(raw_sph_obj, s->sph_obj.data(), d->n_spheres));
+        PT_HIP(s->tris.ensure(3 * static_cast<size_t>(d->n_triangles)));
+        PT_HIP(s->tri_shade.ensure(8 * static_cast<size_t>(d->n_triangles)));
+        PT_HIP(s->spheres.ensure(d->n_spheres));
+        PT_HIP(s->sph_meta.ensure(d->n_spheres));
+        s->build_ms[1] = ms_since(t_upload);
+
+        PtBuildInput in;
+        in.n_objects = d->n_objects;
+        in.n_triangles = d->n_triangles;
+        in.n_spheres = d->n_spheres;
+        in.tri_pos = raw_pos.ptr;
+        in.tri_nrm = d->tri_nrm != nullptr ? raw_nrm.ptr : nullptr;
+        in.tri_cull = raw_cull.ptr;
+        in.tri_material = raw_tri_mat.ptr;
+        in.tri_obj = raw_tri_obj.ptr;
+        in.sph = raw_sph.ptr;
+        in.sph_material = raw_sph_mat.ptr;
+        in.sph_obj = raw_sph_obj.ptr;
+        in.align_siblings = align_siblings;
+        PtBuildOutput built;
+        built.tris = reinterpret_cast<float4 *>(s->tris.ptr);
+        built.tri_shade = reinterpret_cast<float4 *>(s->tri_shade.ptr);
+        built.spheres = reinterpret_cast<float4 *>(s->spheres.ptr);
+        built.sph_meta = s->sph_meta.ptr;
+        const char *what = "";
+        const hipError_t e = pt_build_scene_device(s->stream, in, built, &what);
+        if(e != hipSuccess) {
+            return fail(PT_ERR_HIP, std::string("device scene build (") + what + "): " + hipGetErrorString(e));
         }
+        s->pairs.ptr = reinterpret_cast<F4 *>(built.pairs);
+        s->pairs.count = 4 * static_cast<size_t>(built.n_pairs);
+        DevBuf<uint32_t> dfs_dev;
+        dfs_dev.ptr = built.dfs;
+        dfs_dev.count = d->n_objects;
+        s->build_ms[2] = built.build_ms;
+        s->depth = built.depth;
+        if(s->depth > PT_MAX_DEPTH) {
+            return fail(PT_ERR_UNSUPPORTED, "BVH deeper than 128 levels");
+        }
+        n_pairs = built.n_pairs;
+        root_ref = built.root_ref;
         for(int k = 0; k < 3; k++) {
-            shade[8 * static_cast<size_t>(t) + k] = tris[3 * static_cast<size_t>(t) + k];
+            root_lo[k] = built.root_lo[k];
+            root_hi[k] = built.root_hi[k];
         }
-        shade[8 * static_cast<size_t>(t) + 3] = {na.x, na.y, na.z, nb.x};
-        shade[8 * static_cast<size_t>(t) + 4] = {nb.y, nb.z, nc.x, nc.y};
-        shade[8 * static_cast<size_t>(t) + 5] = {nc.z, 0.0F, 0.0F, 0.0F};
+        // Only objects with an emissive material matter to registerEmissiveObjects: pick them out in construction order on the
+        // host (sequential reads) and let the device put them into depth-first order.
+        std::vector<uint8_t> lit(d->n_materials, 0);
+        bool any_lit = false;
+        for(uint32_t m = 0; m < d->n_materials; m++) {
+            const float *e = d->materials[m].emission;
+            lit[m] = (e[0] + e[1] + e[2]) * e[3] > 0.0F ? 1 : 0;
+            any_lit = any_lit || lit[m] != 0;
+        }
+        if(any_lit) {
+            std::vector<uint32_t> mask((static_cast<size_t>(d->n_objects) + 31) / 32, 0U);
+            uint32_t n_selected = 0;
+            for(uint32_t t = 0; t < d->n_triangles; t++) {
+                const uint32_t m = d->tri_material[t];
+                if(m != PT_NO_MATERIAL && lit[m] != 0) {
+                    const uint32_t o = s->tri_obj[t];
+                    mask[o >> 5] |= 1U << (o & 31U);
+                    n_selected++;
+                }
+            }
+            for(uint32_t i = 0; i < d->n_spheres; i++) {
+                const uint32_t m = d->sph_material[i];
+                if(m != PT_NO_MATERIAL && lit[m] != 0) {
+                    const uint32_t o = s->sph_obj[i];
+                    mask[o >> 5] |= 1U << (o & 31U);
+                    n_selected++;
+                }
+            }
+            std::vector<uint32_t> ordered;
+            PT_HIP(pt_build_order_subset(s->stream, dfs_dev.ptr, d->n_objects, mask, n_selected, ordered));
+            dfs.assign(ordered.begin(), ordered.end());
+        }
     }
-    std::vector<F4> spheres(d->n_spheres);
-    std::vector<uint2> sph_meta(d->n_spheres);
-    for(uint32_t i = 0; i < d->n_spheres; i++) {
-        const float *sp = d->sph + 4 * static_cast<size_t>(i);
-        spheres[i] = {sp[0], sp[1], sp[2], sp[3]};
-        sph_meta[i] = make_uint2(d->sph_material[i], s->sph_obj[i]);
+    else {
+        // ---- host: leaf boxes, the recursion of pt_bvh.cpp, breadth-first flattening, records -----------------------------------
+        std::vector<ptb::Box> boxes(d->n_objects);
+        for(uint32_t i = 0; i < d->n_objects; i++) {
+            ptb::Box &b = boxes[i];
+            const uint32_t idx = leaf_ref[i] & PT_REF_INDEX;
+            if((leaf_ref[i] & PT_REF_SPHERE) == 0) {
+                const float *p = d->tri_pos + 9 * static_cast<size_t>(idx);
+                for(int k = 0; k < 3; k++) { // Triangle::getBoundingVolume, object.cpp:184-186
+                    b.lo[k] = fmin_std(fmin_std(p[k], p[3 + k]), p[6 + k]);
+                    b.hi[k] = fmax_std(fmax_std(p[k], p[3 + k]), p[6 + k]);
+                }
+            }
+            else {
+                const float *sp = d->sph + 4 * static_cast<size_t>(idx);
+                for(int k = 0; k < 3; k++) { // Sphere::getBoundingVolume, object.cpp:90-93
+                    b.lo[k] = sp[k] - sp[3];
+                    b.hi[k] = sp[k] + sp[3];
+                }
+            }
+        }
+        int threads = env_int("PT_BUILD_THREADS", static_cast<int>(std::thread::hardware_concurrency()));
+        threads = std::max(1, std::min(threads, 64));
+        s->tree = ptb::build_reference_bvh(boxes, threads);
+        s->depth = s->tree.depth;
+        if(s->depth > PT_MAX_DEPTH) {
+            return fail(PT_ERR_UNSUPPORTED, "BVH deeper than 128 levels");
+        }
+        ptb::FlatBvh flat = ptb::flatten_breadth_first(s->tree, leaf_ref, align_siblings);
+        n_pairs = flat.n_pairs;
+        root_ref = flat.root_ref;
+        for(int k = 0; k < 3; k++) {
+            root_lo[k] = flat.root_box.lo[k];
+            root_hi[k] = flat.root_box.hi[k];
+        }
+        ptb::leaves_depth_first(s->tree, dfs);
+        s->build_ms[0] = ms_since(t_begin);
+        const auto t_upload = clock::now();
+
+        std::vector<F4> tris(3 * static_cast<size_t>(d->n_triangles)), shade(8 * static_cast<size_t>(d->n_triangles), F4{0.0F, 0.0F, 0.0F, 0.0F});
+        for(uint32_t t = 0; t < d->n_triangles; t++) {
+            const float *p = d->tri_pos + 9 * static_cast<size_t>(t);
+            const Vec3 a = ld(p), b = ld(p + 3), c = ld(p + 6);
+            const Vec3 ab = sub(b, a), ac = sub(c, a);
+            const uint32_t obj_cull = s->tri_obj[t] | (d->tri_cull[t] != 0 ? 0x80000000U : 0U);
+            tris[3 * static_cast<size_t>(t) + 0] = {a.x, a.y, a.z, ab.x};
+            tris[3 * static_cast<size_t>(t) + 1] = {ab.y, ab.z, ac.x, ac.y};
+            tris[3 * static_cast<size_t>(t) + 2] = {ac.z, from_bits(d->tri_material[t]), from_bits(obj_cull), 0.0F};
+            Vec3 na, nb, nc;
+            if(d->tri_nrm != nullptr) {
+                const float *q = d->tri_nrm + 9 * static_cast<size_t>(t);
+                na = ld(q);
+                nb = ld(q + 3);
+                nc = ld(q + 6);
+            }
+            else {
+                na = nb = nc = normalize(cross(ab, ac)); // Triangle::Triangle, object.cpp:118-124
+            }
+            for(int k = 0; k < 3; k++) {
+                shade[8 * static_cast<size_t>(t) + k] = tris[3 * static_cast<size_t>(t) + k];
+            }
+            shade[8 * static_cast<size_t>(t) + 3] = {na.x, na.y, na.z, nb.x};
+            shade[8 * static_cast<size_t>(t) + 4] = {nb.y, nb.z, nc.x, nc.y};
+            shade[8 * static_cast<size_t>(t) + 5] = {nc.z, 0.0F, 0.0F, 0.0F};
+        }
+        std::vector<F4> spheres(d->n_spheres);
+        std::vector<uint2> sph_meta(d->n_spheres);
+        for(uint32_t i = 0; i < d->n_spheres; i++) {
+            const float *sp = d->sph + 4 * static_cast<size_t>(i);
+            spheres[i] = {sp[0], sp[1], sp[2], sp[3]};
+            sph_meta[i] = make_uint2(d->sph_material[i], s->sph_obj[i]);
+        }
+        std::vector<F4> pairs(4 * static_cast<size_t>(flat.n_pairs));
+        std::memcpy(pairs.data(), flat.pairs.data(), flat.pairs.size() * sizeof(float));
+        PT_HIP(s->pairs.upload(pairs));
+        PT_HIP(s->tris.upload(tris));
+        PT_HIP(s->tri_shade.upload(shade));
+        PT_HIP(s->spheres.upload(spheres));
+        PT_HIP(s->sph_meta.upload(sph_meta));
+        s->build_ms[1] = ms_since(t_upload);
     }
+    const auto t_rest = clock::now();
+
     std::vector<F4> materials(4 * static_cast<size_t>(d->n_materials));
     for(uint32_t i = 0; i < d->n_materials; i++) {
         const pt_material &m = d->materials[i];
@@ -827,8 +985,6 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     }
 
     // ---- emissive objects: Scene::registerEmissiveObjects + CDF (scene.cpp:183-208, 167-180) -----------------------------------
-    std::vector<int32_t> dfs;
-    ptb::leaves_depth_first(s->tree, dfs);
     std::vector<F4> emis;
     std::vector<float> cdf;
     const float pi = static_cast<float>(M_PI);
@@ -895,13 +1051,6 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     }
 
     // ---- upload --------------------------------------------------------------------------------------------------------------
-    std::vector<F4> pairs(4 * static_cast<size_t>(flat.n_pairs));
-    std::memcpy(pairs.data(), flat.pairs.data(), flat.pairs.size() * sizeof(float));
-    PT_HIP(s->pairs.upload(pairs));
-    PT_HIP(s->tris.upload(tris));
-    PT_HIP(s->tri_shade.upload(shade));
-    PT_HIP(s->spheres.upload(spheres));
-    PT_HIP(s->sph_meta.upload(sph_meta));
     PT_HIP(s->materials.upload(materials));
     PT_HIP(s->lights.upload(lights));
     PT_HIP(s->emis.upload(emis));
@@ -918,11 +1067,11 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     dev.emis = reinterpret_cast<const float4 *>(s->emis.ptr);
     dev.emis_cdf = s->emis_cdf.ptr;
     for(int k = 0; k < 3; k++) {
-        dev.root_lo[k] = flat.root_box.lo[k];
-        dev.root_hi[k] = flat.root_box.hi[k];
+        dev.root_lo[k] = root_lo[k];
+        dev.root_hi[k] = root_hi[k];
     }
-    dev.root_ref = flat.root_ref;
-    dev.n_pairs = flat.n_pairs;
+    dev.root_ref = root_ref;
+    dev.n_pairs = n_pairs;
     dev.n_tris = d->n_triangles;
     dev.n_spheres = d->n_spheres;
     dev.n_lights = d->n_point_lights;
@@ -931,19 +1080,24 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     // LDS staging: a scene whose whole tree and triangle records fit in 24 KiB lives in LDS entirely; for larger scenes the
     // traversal kernel is bound by instruction issue, not by node latency, and an LDS copy of the top of the tree only costs
     // occupancy (measured: profiles/), so it is off unless PT_LDS_PAIRS asks for it.
-    const size_t small_bytes = static_cast<size_t>(flat.n_pairs) * 64 + static_cast<size_t>(d->n_triangles) * 48;
+    const size_t small_bytes = static_cast<size_t>(n_pairs) * 64 + static_cast<size_t>(d->n_triangles) * 48;
     if(small_bytes <= 24 * 1024 && env_int("PT_LDS_SMALL", 1) != 0) {
-        dev.n_lds_pairs = flat.n_pairs;
+        dev.n_lds_pairs = n_pairs;
         dev.n_lds_tris = d->n_triangles;
     }
     else {
-        dev.n_lds_pairs = std::min(flat.n_pairs, static_cast<uint32_t>(std::max(env_int("PT_LDS_PAIRS", 0), 0)));
+        dev.n_lds_pairs = std::min(n_pairs, static_cast<uint32_t>(std::max(env_int("PT_LDS_PAIRS", 0), 0)));
         dev.n_lds_tris = 0;
     }
 
     int rc = setup_trace(s.get());
     if(rc != PT_OK) {
         return rc;
+    }
+    s->build_ms[3] = ms_since(t_rest);
+    if(env_int("PT_DEBUG", 0) != 0) {
+        std::fprintf(stderr, "[pt] scene build (%s): %u objects, %u pair records, depth %u; host preparation %.1f ms, upload %.1f ms, device tree %.1f ms, rest %.1f ms\n",
+                     s->device_built ? "device" : "host", d->n_objects, n_pairs, s->depth, s->build_ms[0], s->build_ms[1], s->build_ms[2], s->build_ms[3]);
     }
     *out = s.release();
     return PT_OK;
@@ -975,10 +1129,10 @@ int pt_scene_info(const pt_scene *scene, uint64_t *n_nodes, uint32_t *depth, uin
         return fail(PT_ERR_INVALID, "null scene");
     }
     if(n_nodes != nullptr) {
-        *n_nodes = scene->tree.nodes.size();
+        *n_nodes = scene->n_nodes;
     }
     if(depth != nullptr) {
-        *depth = scene->tree.depth;
+        *depth = scene->depth;
     }
     if(n_emissive != nullptr) {
         *n_emissive = scene->n_emissive;
@@ -1011,7 +1165,49 @@ int pt_scene_bvh_dump(const pt_scene *scene, int32_t *out_obj, float *out_box, u
     }
     std::vector<int32_t> obj;
     std::vector<ptb::Box> box;
-    ptb::dump_preorder(scene->tree, obj, box);
+    if(!scene->device_built) {
+        ptb::dump_preorder(scene->tree, obj, box);
+    }
+    else {
+        // rebuild the pre-order listing from the pair records in HBM
+        std::vector<F4> pairs(scene->pairs.count);
+        if(hipSetDevice(scene->device) != hipSuccess ||
+           hipMemcpy(pairs.data(), scene->pairs.ptr, pairs.size() * sizeof(F4), hipMemcpyDeviceToHost) != hipSuccess) {
+            return fail(PT_ERR_HIP, "downloading the pair records failed");
+        }
+        struct Item {
+            uint32_t ref;
+            ptb::Box box;
+        };
+        ptb::Box root;
+        for(int k = 0; k < 3; k++) {
+            root.lo[k] = scene->dev.root_lo[k];
+            root.hi[k] = scene->dev.root_hi[k];
+        }
+        std::vector<Item> stack{{scene->dev.root_ref, root}};
+        obj.reserve(scene->n_nodes);
+        box.reserve(scene->n_nodes);
+        while(!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            box.push_back(it.box);
+            if((it.ref & PT_REF_LEAF) != 0) {
+                const uint32_t idx = it.ref & PT_REF_INDEX;
+                obj.push_back(static_cast<int32_t>((it.ref & PT_REF_SPHERE) != 0 ? scene->sph_obj[idx] : scene->tri_obj[idx]));
+            }
+            else {
+                obj.push_back(-1);
+                const float *q = &pairs[4 * static_cast<size_t>(it.ref)].x;
+                Item l, r;
+                std::memcpy(&l.box, q, 24);
+                std::memcpy(&r.box, q + 6, 24);
+                std::memcpy(&l.ref, q + 12, 4);
+                std::memcpy(&r.ref, q + 13, 4);
+                stack.push_back(r);
+                stack.push_back(l);
+            }
+        }
+    }
     const uint64_t n = std::min<uint64_t>(obj.size(), capacity);
     for(uint64_t i = 0; i < n; i++) {
         out_obj[i] = obj[i];

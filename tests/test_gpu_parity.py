@@ -121,6 +121,68 @@ def test_process_job_vs_oracle(gpu_scenes, sset, oracle_lib, name, w, h, mn, mx)
     assert same == 1.0, "only %.4f of the pixels are bit-identical" % same
 
 
+def _scene_with(mode, desc):
+    import os
+    old = os.environ.get("PT_BUILD")
+    os.environ["PT_BUILD"] = mode
+    try:
+        return binding.Scene(desc)
+    finally:
+        if old is None:
+            del os.environ["PT_BUILD"]
+        else:
+            os.environ["PT_BUILD"] = old
+
+
+def _tie_heavy_scene():
+    """Many equal low coordinates: the stable partition keeps all ties on the left and scene.cpp:89-94 has to move objects."""
+    rng = np.random.default_rng(77)
+    sb = scenes.SceneBuilder()
+    lit = sb.material((1, 1, 1, 1), 1.0, (2, 1, 0.5, 1))
+    one = np.array([[[0.1, 0.2, 0.3], [0.4, 0.2, 0.3], [0.1, 0.5, 0.6]]], np.float32)
+    sb.triangles(np.repeat(one, 700, axis=0))                                    # 700 identical triangles
+    grid = np.floor(rng.uniform(-4, 4, (1500, 1, 3))).astype(np.float32) * np.float32(0.25)
+    sb.triangles(grid + rng.uniform(0, 0.2, (1500, 3, 3)).astype(np.float32) * np.array([[[0, 0, 0]], [[1, 1, 1]], [[1, 1, 1]]], np.float32).reshape(1, 3, 3))
+    sb.triangles(np.repeat(one + np.float32(1.0), 130, axis=0), lit, cull=True)   # identical AND emissive
+    sb.sphere((0.3, 0.1, -0.2), 0.25, sb.material((0, 0, 1, 1), bsdf=scenes.BSDF_MIRROR))
+    sb.sphere((0.3, 0.1, -0.2), 0.25, lit)
+    sb.triangles(rng.uniform(-1, 1, (900, 3, 3)).astype(np.float32), lit)
+    return sb.build()
+
+
+@pytest.mark.parametrize("name", SCENES + ["dragons16", "ties", "ties_face_normals"])
+def test_device_build_matches_host_build(sset, oracle_lib, name):
+    """the tree built level by level on the device (pt_build.hip) against the host recursion (pt_bvh.cpp) and the
+    CPU oracle: same pre-order topology, same boxes bit for bit, same emissive registration order and CDF, same closest hits."""
+    desc = _tie_heavy_scene() if name.startswith("ties") else sset[name][0]
+    oracle_desc = desc
+    if name == "ties_face_normals":
+        desc = dict(desc, tri_nrm=None)  # Triangle::Triangle without normals: face normals made by the record kernel
+    dev, host = _scene_with("device", desc), _scene_with("host", desc)
+    try:
+        (od, bd), (oh, bh) = dev.bvh_dump(), host.bvh_dump()
+        assert_bits_equal(od, oh, "topology, device build vs host build")
+        assert_bits_equal(bd, bh, "boxes, device build vs host build")
+        oo, bo = oracle_lib.bvh_dump(oracle_desc)  # normals play no part in the tree
+        assert_bits_equal(od, oo, "topology, device build vs oracle")
+        assert_bits_equal(bd, bo, "boxes, device build vs oracle")
+        assert dev.info() == host.info()
+        for a, b in zip(dev.emissive(), host.emissive()):
+            assert_bits_equal(a, b, "emissive objects / CDF")
+        rng = np.random.default_rng(11)
+        d = rng.normal(size=(20000, 3))
+        rays = np.concatenate([rng.uniform(-1, 1, (20000, 3)), d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1).astype(np.float32)
+        (td, hd), (th, hh) = dev.get_intersection(rays), host.get_intersection(rays)
+        assert_bits_equal(td, th, "closest hit t")
+        assert_bits_equal(hd, hh, "closest hit object")
+        cam = scenes.camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, -1.0)
+        opt = scenes.options(24, 24, 4, 4)
+        assert_bits_equal(dev.process_job(cam, opt, base_seed=5), host.process_job(cam, opt, base_seed=5), "rendered frame")
+    finally:
+        dev.close()
+        host.close()
+
+
 def test_reference_render_tests(gpu_scenes, sset):
     """test/render_test.cpp: empty scene -> exact zero; simple and advanced scenes -> zero corner, centre alpha > 0."""
     sc, cam = scenes.empty_scene()

@@ -21,13 +21,24 @@ PT_OK = 0
 ERRORS = {1: "PT_ERR_INVALID", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR_HIP", 4: "PT_ERR_UNSUPPORTED", 5: "PT_ERR_NOMEM"}
 
 EXPORTS = ["pt_device_count", "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_scene_info", "pt_scene_emissive", "pt_scene_bvh_dump", "pt_intersect_batch",
-           "pt_render_streams", "pt_render_tiles", "pt_render_tiles_device", "pt_job_tiles", "pt_pixel_seed", "pt_rng_seed_to_state"]
+           "pt_render_streams", "pt_render_tiles", "pt_render_tiles_device", "pt_job_tiles", "pt_pixel_seed", "pt_rng_seed_to_state", "pt_post_process", "pt_post_process_device"]
 
 
 class PtError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("%s: %s" % (ERRORS.get(code, code), message))
         self.code = code
+
+
+POST_TONE_MAP, POST_GAMMA = 1, 2
+
+
+def post_process(image, steps=POST_TONE_MAP | POST_GAMMA, gamma=1.8, device=0):
+    """toneMap / gammaCorrect / postProcess (post_processing.h:14,22,30) of an (h, w, 4) float32 frame on the GPU; returns a new array."""
+    img = np.array(image, dtype=np.float32, order="C", copy=True)
+    h, w = img.shape[:2]
+    _check(load().pt_post_process(C.c_int(device), _ptr(img), C.c_int32(w), C.c_int32(h), C.c_uint32(steps), C.c_float(gamma)))
+    return img
 
 
 class SceneDesc(C.Structure):

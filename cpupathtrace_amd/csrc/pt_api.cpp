@@ -21,6 +21,7 @@
 #include "pt_build.h"
 #include "pt_bvh.h"
 #include "pt_kernels.h"
+#include "pt_post.h"
 
 #define PT_MAX_GROUPS 8 /* independent slices of the streams pipelined on separate HIP streams */
 
@@ -1438,3 +1439,54 @@ int pt_render_tiles_device(pt_scene *s, const pt_camera_params *camera, const pt
 }
 
 } // extern "C"
+
+// ---- post-processing (pt_post.hip) ----------------------------------------------------------------------------------------------
+
+static int post_check(int device, const float *rgba, int32_t width, int32_t height, uint32_t steps, float gamma) {
+    if(width < 0 || height < 0 || (rgba == nullptr && static_cast<long long>(width) * height > 0)) {
+        return fail(PT_ERR_INVALID, "bad image");
+    }
+    if((steps & ~(PT_POST_TONE_MAP | PT_POST_GAMMA)) != 0 || steps == 0) {
+        return fail(PT_ERR_INVALID, "steps must be PT_POST_TONE_MAP and/or PT_POST_GAMMA");
+    }
+    if((steps & PT_POST_GAMMA) != 0 && !(gamma == gamma)) {
+        return fail(PT_ERR_INVALID, "gamma is NaN");
+    }
+    const int n_dev = device_count_quiet();
+    if(n_dev <= 0) {
+        return fail(PT_ERR_NO_DEVICE, "no HIP device available; libpathtrace_hip has no CPU path");
+    }
+    if(device < 0 || device >= n_dev) {
+        return fail(PT_ERR_NO_DEVICE, "device index out of range");
+    }
+    return PT_OK;
+}
+
+int pt_post_process_device(int device, float *d_rgba, int32_t width, int32_t height, uint32_t steps, float gamma, void *stream) {
+    const int rc = post_check(device, d_rgba, width, height, steps, gamma);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    PT_HIP(hipSetDevice(device));
+    static_assert(PT_POST_TONE_MAP == PT_POST_STEP_TONE_MAP && PT_POST_GAMMA == PT_POST_STEP_GAMMA, "step bits");
+    PT_HIP(pt_post_run(static_cast<hipStream_t>(stream), reinterpret_cast<float4 *>(d_rgba), width, height, steps, gamma));
+    return PT_OK;
+}
+
+int pt_post_process(int device, float *rgba, int32_t width, int32_t height, uint32_t steps, float gamma) {
+    const int rc = post_check(device, rgba, width, height, steps, gamma);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    const size_t count = static_cast<size_t>(width) * static_cast<size_t>(height);
+    if(count == 0) {
+        return PT_OK;
+    }
+    PT_HIP(hipSetDevice(device));
+    DevBuf<F4> frame;
+    PT_HIP(frame.ensure(count));
+    PT_HIP(hipMemcpy(frame.ptr, rgba, count * sizeof(F4), hipMemcpyHostToDevice));
+    PT_HIP(pt_post_run(nullptr, reinterpret_cast<float4 *>(frame.ptr), width, height, steps, gamma));
+    PT_HIP(hipMemcpy(rgba, frame.ptr, count * sizeof(F4), hipMemcpyDeviceToHost));
+    return PT_OK;
+}

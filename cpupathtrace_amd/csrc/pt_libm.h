@@ -178,6 +178,96 @@ PT_HD float powf_glibc(float x, float y) {
     return (float)powf_exp2(ylogx);
 }
 
+// The whole of powf (glibc 2.35 sysdeps/ieee754/flt-32/e_powf.c with TOINT_INTRINSICS == 0): every x, every y.  Used by the gamma
+// correction (post_processing.cpp:171-182), whose base is any non-negative radiance and whose exponent 1 / gamma - 1 has either sign.
+PT_HD int powf_checkint(uint32_t iy) {
+    const int e = (int)(iy >> 23 & 0xff);
+    if(e < 0x7f) {
+        return 0;
+    }
+    if(e > 0x7f + 23) {
+        return 2;
+    }
+    if(iy & ((1u << (0x7f + 23 - e)) - 1)) {
+        return 0;
+    }
+    if(iy & (1u << (0x7f + 23 - e))) {
+        return 1;
+    }
+    return 2;
+}
+PT_HD bool powf_zeroinfnan(uint32_t ix) {
+    return 2 * ix - 1 >= 2u * 0x7f800000u - 1;
+}
+PT_HD float powf_glibc_full(float x, float y) {
+    bool negate = false;
+    uint32_t ix = as_u32(x), iy = as_u32(y);
+    if(ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy)) {
+        // either (x < 0x1p-126 or inf or nan) or (y is 0 or inf or nan)
+        if(powf_zeroinfnan(iy)) {
+            if(2 * iy == 0) {
+                return 1.0f; // (signalling NaNs are not distinguished: both operands are quiet on this path)
+            }
+            if(ix == 0x3f800000u) {
+                return 1.0f;
+            }
+            if(2 * ix > 2u * 0x7f800000u || 2 * iy > 2u * 0x7f800000u) {
+                return x + y;
+            }
+            if(2 * ix == 2 * 0x3f800000u) {
+                return 1.0f;
+            }
+            if((2 * ix < 2 * 0x3f800000u) == !(iy & 0x80000000u)) {
+                return 0.0f; // |x| < 1 && y == inf or |x| > 1 && y == -inf
+            }
+            return y * y;
+        }
+        if(powf_zeroinfnan(ix)) {
+            float x2 = x * x;
+            if((ix & 0x80000000u) && powf_checkint(iy) == 1) {
+                x2 = -x2;
+                negate = true;
+            }
+            if(2 * ix == 0 && (iy & 0x80000000u)) {
+                return (negate ? -1.0f : 1.0f) / 0.0f;
+            }
+            return (iy & 0x80000000u) ? 1 / x2 : x2;
+        }
+        // x and y are non-zero finite
+        if(ix & 0x80000000u) {
+            const int yint = powf_checkint(iy);
+            if(yint == 0) {
+                return (x - x) / (x - x);
+            }
+            if(yint == 1) {
+                negate = true;
+            }
+            ix &= 0x7fffffffu;
+        }
+        if(ix < 0x00800000u) {
+            // normalise a subnormal x so that the exponent becomes negative
+            ix = as_u32(x * 0x1p23f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    const double logx = powf_log2(ix);
+    const double ylogx = y * logx; // cannot overflow, y is single precision
+    if((as_u64(ylogx) >> 47 & 0xffff) >= (as_u64(126.0) >> 47)) {
+        // |y * log(x)| >= 126
+        if(ylogx > 0x1.fffffffd1d571p+6) {
+            const float big = negate ? -0x1p97f : 0x1p97f;
+            return big * 0x1p97f;
+        }
+        if(ylogx <= -150.0) {
+            const float tiny = negate ? -0x1p-95f : 0x1p-95f;
+            return tiny * 0x1p-95f;
+        }
+    }
+    const float r = (float)powf_exp2(ylogx);
+    return negate ? -r : r;
+}
+
 // ---- acosf ---------------------------------------------------------------------------------------------------------
 
 // correctly rounded on both sides: hipcc keeps -fhip-fp32-correctly-rounded-divide-sqrt on by default

@@ -165,6 +165,16 @@ uint64_t pt_pixel_seed(uint64_t base_seed, int32_t x, int32_t y);
 /* RandomEngine(seed) raw state (base.h:26). */
 uint64_t pt_rng_seed_to_state(uint64_t seed);
 
+/* toneMap / gammaCorrect / postProcess (include/PathTrace/post_processing.h:14,22,30; src/post_processing.cpp:32-187) on an
+ * rgba f32 frame (row-major, y * width + x as image/image.h:82), in place.  `steps` = PT_POST_TONE_MAP | PT_POST_GAMMA; both =
+ * postProcess (tone mapping first).  `gamma` is gammaCorrect's argument (the reference's default is 1.8).
+ * pt_post_process takes a HOST buffer (uploads, processes, downloads); pt_post_process_device works on DEVICE memory and is
+ * ordered on `stream` (a hipStream_t, NULL = the default stream), which it synchronises before returning. */
+#define PT_POST_TONE_MAP 1u
+#define PT_POST_GAMMA 2u
+int pt_post_process(int device, float *rgba, int32_t width, int32_t height, uint32_t steps, float gamma);
+int pt_post_process_device(int device, float *d_rgba, int32_t width, int32_t height, uint32_t steps, float gamma, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

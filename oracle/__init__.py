@@ -276,6 +276,14 @@ class Checker:
                                  C.c_void_p(_ptr(states)), C.c_void_p(_ptr(rays)), C.c_void_p(_ptr(st)))
         return rays, st
 
+    # ---- post-processing ----
+    def post_process(self, image, steps=3, gamma=1.8):
+        """steps: 1 = toneMap, 2 = gammaCorrect(gamma), 3 = postProcess (post_processing.h:14,22,30); returns a new (h, w, 4) array."""
+        img = np.array(image, dtype=np.float32, order="C", copy=True)
+        h, w = img.shape[:2]
+        self._fn("post_process")(C.c_void_p(_ptr(img)), C.c_int(w), C.c_int(h), C.c_int(steps), C.c_float(gamma))
+        return img
+
     # ---- scene ----
     def scene_create(self, scene):
         d, keep = scene_desc(scene)

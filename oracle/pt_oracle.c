@@ -1719,3 +1719,135 @@ void oracle_render_streams(void *h, const pto_camera_params *cp, const pto_optio
     }
     pthread_mutex_destroy(&job.lock);
 }
+
+/* ---- post-processing: toneMap / gammaCorrect (src/post_processing.cpp:11-187), sequential restatement ------------------------------ */
+
+static float post_peak(const float *c) { /* std::max({r, g, b}) */
+    float m = c[0];
+    m = (m < c[1]) ? c[1] : m;
+    m = (m < c[2]) ? c[2] : m;
+    return m;
+}
+
+static float post_heuristic(const float *c) { /* getBrightnessHeuristic, :27-30 */
+    return c[3] * ((c[0] + c[1] + c[2]) / 3.0F + post_peak(c)) / 2.0F;
+}
+
+static int post_cmp(const void *a, const void *b) {
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+static float post_gaussian(float t, float mu, float sigma) { /* :11-20 */
+    const float pi = (float)M_PI;
+    const float fac = 1.0F / (sqrtf(2 * pi));
+    const float exponent_part = (t - mu) / (sigma);
+    return fac * expf(-(exponent_part * exponent_part) / 2.0F) / sigma;
+}
+
+static void post_tone_map(float *rgba, int width, int height) { /* :32-166 */
+    const int pixel_count = width * height;
+    if(pixel_count <= 0) {
+        return;
+    }
+    float min_brightness = 0.0F, max_brightness = 1E-4F;
+    float *values = (float *)malloc(sizeof(float) * (size_t)pixel_count);
+    for(int i = 0; i < pixel_count; i++) {
+        const float b = post_heuristic(rgba + 4 * (size_t)i);
+        values[i] = b;
+        min_brightness = (b < min_brightness) ? b : min_brightness;
+        max_brightness = (max_brightness < b) ? b : max_brightness;
+    }
+    /* buckets of equal width in brightness, each sorted, concatenated (:49-88) == the sorted list */
+    qsort(values, (size_t)pixel_count, sizeof(float), post_cmp);
+
+    const int segments = pixel_count < 1024 ? pixel_count : 1024;
+    float *weights = (float *)malloc(sizeof(float) * (size_t)segments);
+    float *ceilings = (float *)malloc(sizeof(float) * (size_t)segments);
+    float total = 0.0F;
+    for(int i = 0; i < segments; i++) {
+        float x = ((float)i + 0.5F) / (float)segments;
+        x = 2.0F * (x - 0.5F);
+        weights[i] = 0.1F + post_gaussian(x, 0.0F, 0.3F);
+        total += weights[i];
+    }
+    int previous_index = 0;
+    float missed = 0.0F;
+    for(int i = 0; i < segments - 1; i++) {
+        const int count = (int)roundf(weights[i] * (float)pixel_count / total + missed);
+        if(count > 0) {
+            int index = previous_index + count - 1;
+            if(index > pixel_count - 1) {
+                index = pixel_count - 1;
+            }
+            ceilings[i] = values[index];
+            previous_index += count;
+            missed = 0.0F;
+        }
+        else {
+            ceilings[i] = i > 0 ? ceilings[i - 1] : min_brightness;
+            missed += weights[i] * (float)pixel_count / total;
+        }
+    }
+    ceilings[segments - 1] = max_brightness;
+
+    const float tiny = 1.17549435e-38F;
+    for(int i = 0; i < pixel_count; i++) {
+        float *c = rgba + 4 * (size_t)i;
+        const float peak = post_peak(c);
+        const float brightness = (peak < tiny) ? tiny : peak;
+        const float h = post_heuristic(c);
+        int lo = 0, len = segments; /* std::lower_bound */
+        while(len > 0) {
+            const int half = len >> 1;
+            if(ceilings[lo + half] < h) {
+                lo = lo + half + 1;
+                len = len - half - 1;
+            }
+            else {
+                len = half;
+            }
+        }
+        const int index = lo < segments ? lo : segments - 1;
+        const float upper = ceilings[index];
+        const float lower = index > 0 ? ceilings[index - 1] : min_brightness;
+        const float diff = upper - lower;
+        const float span = (diff < tiny) ? tiny : diff;
+        const float value = (h - lower) / span;
+        const float mapped_upper = (float)(index + 1) / (float)segments;
+        const float mapped_lower = (float)index / (float)segments;
+        const float mapped_span = mapped_upper - mapped_lower;
+        const float mapped_value = mapped_lower + value * mapped_span;
+        const float factor = mapped_value / brightness;
+        c[0] *= factor;
+        c[1] *= factor;
+        c[2] *= factor;
+    }
+    free(values);
+    free(weights);
+    free(ceilings);
+}
+
+static void post_gamma(float *rgba, int width, int height, float gamma) { /* :171-182 */
+    for(long long i = 0; i < (long long)width * height; i++) {
+        float *c = rgba + 4 * (size_t)i;
+        const float factor = powf(post_peak(c), 1.0F / gamma - 1.0F);
+        c[0] *= factor;
+        c[1] *= factor;
+        c[2] *= factor;
+    }
+}
+
+/* steps: 1 = toneMap, 2 = gammaCorrect(gamma), 3 = postProcess (gamma 1.8, post_processing.h:22) */
+void oracle_post_process(float *rgba, int width, int height, int steps, float gamma) {
+    if(steps == 3) {
+        post_tone_map(rgba, width, height);
+        post_gamma(rgba, width, height, 1.8F);
+    }
+    else if(steps == 1) {
+        post_tone_map(rgba, width, height);
+    }
+    else if(steps == 2) {
+        post_gamma(rgba, width, height, gamma);
+    }
+}

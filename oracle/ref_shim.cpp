@@ -8,6 +8,7 @@
  * tests/golden/make_golden.py can record what the reference computes and bench.py can time it
  * (cpu_baseline.kind == "reference").  Nothing in the product loads this library.
  */
+#include <PathTrace/post_processing.h>
 #include <PathTrace/base.h>
 #include <PathTrace/camera.h>
 #include <PathTrace/worker.h>
@@ -589,6 +590,34 @@ void ref_mat4_apply(const float *mat16, uint64_t n, const float *in, float *out)
         out[3 * i + 0] = v[0];
         out[3 * i + 1] = v[1];
         out[3 * i + 2] = v[2];
+    }
+}
+
+// steps: 1 = toneMap, 2 = gammaCorrect(gamma), 3 = postProcess (which uses gammaCorrect's default gamma, post_processing.h:22)
+void ref_post_process(float *rgba, int width, int height, int steps, float gamma) {
+    Image<> image(width, height);
+    for(int y = 0; y < height; y++) {
+        for(int x = 0; x < width; x++) {
+            const float *p = rgba + 4 * (static_cast<size_t>(y) * width + x);
+            image(x, y) = Color<float>(p[0], p[1], p[2], p[3]);
+        }
+    }
+    if(steps == 3) {
+        postProcess(image);
+    }
+    else if(steps == 1) {
+        toneMap(image);
+    }
+    else if(steps == 2) {
+        gammaCorrect(image, gamma);
+    }
+    for(int y = 0; y < height; y++) {
+        for(int x = 0; x < width; x++) {
+            float *p = rgba + 4 * (static_cast<size_t>(y) * width + x);
+            for(int c = 0; c < 4; c++) {
+                p[c] = image(x, y)[c];
+            }
+        }
     }
 }
 

@@ -66,3 +66,18 @@ def demo_mesh(mesh):
     return p.reshape(-1, 3, 3).astype(F), mnrm
 
 
+
+
+POST_IMAGES = ["hdr_56x40", "hdr_20x15", "hdr_3x1", "flat_40x32"]
+POST_GAMMAS = [1.8, 1.0, 0.1, 2.0]
+
+
+def post_cases():
+    """(input frame, steps, gamma, expected frame, label) for every entry of tests/golden/post.npz (steps: 1 toneMap, 2 gammaCorrect,
+    3 postProcess)."""
+    g = golden("post")
+    for name in POST_IMAGES:
+        yield g[name], 1, 1.8, g[name + "_tone"], name + " toneMap"
+        for gamma in POST_GAMMAS:
+            yield g[name], 2, gamma, g[name + "_gamma_%g" % gamma], "%s gammaCorrect(%g)" % (name, gamma)
+        yield g[name], 3, 1.8, g[name + "_post"], name + " postProcess"

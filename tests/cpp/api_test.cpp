@@ -4,6 +4,7 @@
 // implementation can promise: processItem is deterministic per engine state and advances the engine, processJob is
 // reproducible under PATHTRACE_SEED, progress is reported once per tile in order, unsupported subclasses are refused.
 #include <PathTrace/camera.h>
+#include <PathTrace/post_processing.h>
 #include <PathTrace/scene/light.h>
 #include <PathTrace/scene/mesh.h>
 #include <PathTrace/scene/object.h>
@@ -13,6 +14,7 @@
 #include <gmock/gmock.h>
 #include <gtest/gtest.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -197,6 +199,56 @@ TEST(Scene, UserDefinedObjectsAreRefusedNotMisrendered) {
         refused = true;
     }
     EXPECT_THAT(refused, testing::Eq(true));
+}
+
+// post-processing runs on the device; what must hold for any frame (post_processing.h:6-12,16-22): sizes are kept, alpha is
+// untouched, tone mapping lands every peak channel in [0, 1] and keeps the order of the brightness heuristic, gamma 1 is the identity
+TEST(Render, PostProcessingOnTheDevice) {
+    Image<> frame(40, 30);
+    uint64_t state = 0x9E3779B97F4A7C15ULL;
+    for(int y = 0; y < frame.getHeight(); y++) {
+        for(int x = 0; x < frame.getWidth(); x++) {
+            float channel[3];
+            for(float &c : channel) {
+                state ^= state << 13;
+                state ^= state >> 7;
+                state ^= state << 17;
+                c = 0.001F + static_cast<float>(state >> 40) / 16777216.0F * static_cast<float>(1 + (x * 7 + y) % 50);
+            }
+            frame(x, y) = Color<float>(channel[0], channel[1], channel[2], 1.0F);
+        }
+    }
+    Image<> same = frame;
+    gammaCorrect(same, 1.0F);
+    EXPECT_THAT(sameBits(same, frame), testing::Eq(true));
+
+    Image<> mapped = frame;
+    toneMap(mapped);
+    EXPECT_THAT(mapped.getWidth(), testing::Eq(frame.getWidth()));
+    EXPECT_THAT(mapped.getHeight(), testing::Eq(frame.getHeight()));
+    auto peak = [](const Color<float> &c) { return std::max({c[0], c[1], c[2]}); };
+    auto heuristic = [&](const Color<float> &c) { return c[3] * ((c[0] + c[1] + c[2]) / 3.0F + peak(c)) / 2.0F; };
+    int out_of_range = 0, order_violations = 0;
+    for(int y = 0; y < frame.getHeight(); y++) {
+        for(int x = 0; x < frame.getWidth(); x++) {
+            const float p = peak(mapped(x, y));
+            out_of_range += !(p >= 0.0F && p <= 1.0F);
+            out_of_range += mapped(x, y)[3] != 1.0F;
+            if(x > 0) {
+                const bool brighter_before = heuristic(frame(x, y)) > heuristic(frame(x - 1, y));
+                const bool brighter_after = peak(mapped(x, y)) >= peak(mapped(x - 1, y));
+                order_violations += brighter_before && !brighter_after;
+            }
+        }
+    }
+    EXPECT_THAT(out_of_range, testing::Eq(0));
+    EXPECT_THAT(order_violations, testing::Eq(0));
+
+    Image<> both = frame, stepwise = frame;
+    postProcess(both);
+    toneMap(stepwise);
+    gammaCorrect(stepwise); // default gamma, 1.8
+    EXPECT_THAT(sameBits(both, stepwise), testing::Eq(true));
 }
 
 int main(int argc, char *argv[]) {

@@ -261,14 +261,52 @@ def gen_scenes(ref):
          cornell_mid_16_64=t4, cornell_mid_state=s4, advanced_edge=t5, advanced_edge_state=s5)
 
 
+def post_images():
+    """Frames for the post-processing fixtures: random HDR radiance with black, tiny and huge pixels; more and fewer than 1024 pixels
+    (toneMap uses min(1024, pixel_count) segments, post_processing.cpp:56,90); a frame that is almost entirely one value."""
+    rng = np.random.default_rng(4242)
+
+    def hdr(h, w):
+        img = np.exp(rng.normal(-1.0, 2.0, (h, w, 4))).astype(F)
+        img[..., 3] = 1.0
+        flat = img.reshape(-1, 4)
+        idx = rng.permutation(len(flat))
+        flat[idx[:7], :3] = 0.0                                   # black pixels: gammaCorrect makes 0 * inf of them
+        flat[idx[7:12], :3] *= F(1e-30)                           # nearly black
+        flat[idx[12:15], :3] *= F(1e6)                            # fireflies
+        if len(flat) > 44:
+            flat[idx[15:40], :3] = flat[idx[15], :3]              # repeated values
+            flat[idx[40:44], 3] = 0.0                             # no samples at all (worker.cpp:263-265 leaves alpha 0)
+        return img
+
+    images = {"hdr_56x40": hdr(40, 56), "hdr_20x15": hdr(15, 20), "hdr_3x1": np.exp(rng.normal(0, 1, (1, 3, 4))).astype(F)}
+    flat = np.full((32, 40, 4), 0.25, F)
+    flat[..., 3] = 1.0
+    flat[5, 7, :3] = (0.5, 0.1, 0.9)
+    images["flat_40x32"] = flat
+    return images
+
+
+def gen_post(ref):
+    # F10: toneMap / gammaCorrect / postProcess (SURVEY.md 8f rank 3)
+    out = {}
+    for name, img in post_images().items():
+        out[name] = img
+        out[name + "_tone"] = ref.post_process(img, 1)
+        for gamma in (1.8, 1.0, 0.1, 2.0):
+            out[name + "_gamma_%g" % gamma] = ref.post_process(img, 2, gamma)
+        out[name + "_post"] = ref.post_process(img, 3)
+    save("post", **out)
+
+
+GENERATORS = {"rng": gen_rng, "prims": gen_prims, "bsdf": gen_bsdf, "camera": gen_camera, "scenes": gen_scenes, "post": gen_post}
+
+
 def main():
     oracle.build()
     ref = oracle.Checker("ref")
-    gen_rng(ref)
-    gen_prims(ref)
-    gen_bsdf(ref)
-    gen_camera(ref)
-    gen_scenes(ref)
+    for name in (sys.argv[1:] or list(GENERATORS)):
+        GENERATORS[name](ref)
 
 
 if __name__ == "__main__":

@@ -75,6 +75,23 @@ int main(int argc, char **argv) {
             bad += ptm::as_u32(acosf(f)) != ptm::as_u32(ptm::acosf_glibc(f));
         }
     }
+    // the general powf (gamma correction): bases over the whole non-negative range incl. subnormals, 0, inf; exponents of both signs
+    const float ys[] = {1.0f / 1.8f - 1.0f, 1.0f / 2.2f - 1.0f, 1.0f / 0.1f - 1.0f, 1.0f / 2.0f - 1.0f, 0.0f, -0.0f, 1.0f, -1.0f, 0.5f, 3.0f, -2.5f, 40.0f, -40.0f, 1e-3f};
+    for(uint32_t u = 0; u <= 0x7f800000u; u += 16 * step + 7, n++) {
+        float f = ptm::as_f32(u);
+        for(float y : ys) {
+            bad += ptm::as_u32(powf(f, y)) != ptm::as_u32(ptm::powf_glibc_full(f, y));
+        }
+    }
+    {
+        uint64_t state = 88172645463325252ULL;
+        for(int i = 0; i < 2000000; i++, n++) {
+            state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+            float f = ptm::as_f32((uint32_t)state), y = ptm::as_f32((uint32_t)(state >> 32));
+            float a = powf(f, y), b = ptm::powf_glibc_full(f, y);
+            bad += (a != a) ? !(b != b) : (ptm::as_u32(a) != ptm::as_u32(b));
+        }
+    }
     printf("%%lu %%lu\n", n, bad);
     return 0;
 }
@@ -84,7 +101,7 @@ int main(int argc, char **argv) {
 @pytest.mark.parametrize("step", [251])
 def test_device_libm_matches_glibc(tmp_path, step):
     """cpupathtrace_amd/csrc/pt_libm.h compiled for the host against the running glibc (2.35 in this image): sinf/cosf on
-    [0, 7], powf(x, 0.5 | 1) on [2^-33, 1], acosf on [-1, 1]; every `step`-th float (step 1 = exhaustive, ~30 s)."""
+    [0, 7], powf(x, 0.5 | 1) on [2^-33, 1], the general powf over all non-negative bases and 2 M random bit patterns, acosf on [-1, 1]; every `step`-th float (step 1 = exhaustive, ~30 s)."""
     src = tmp_path / "libm_check.cpp"
     src.write_text("#include <cstdlib>\n" + LIBM_CHECK % os.path.join(ROOT, "cpupathtrace_amd", "csrc", "pt_libm.h"))
     exe = tmp_path / "libm_check"

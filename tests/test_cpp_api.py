@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "tests", "cpp", "shim")
 REF = "/root/reference"
 REF_OUT = os.path.join(ROOT, "oracle", "_ref")
-GPU_TESTS = "RenderTest,SceneTest"  # tests of the reference's suite that render or query a Scene
+GPU_TESTS = "RenderTest,SceneTest,PostProcessingTest"  # tests of the reference's suite that render, query a Scene or post-process a frame (all on the GPU)
 
 
 def _run(exe, skip=None):
@@ -59,7 +59,7 @@ def test_reference_sources_compile_unchanged():
     build_reference_programs()
     r = _run(os.path.join(REF_OUT, "ref_tests"), skip=GPU_TESTS)
     assert r.returncode == 0, r.stdout + r.stderr
-    for name in ("PostProcessingTest.GammaTest", "AABBTest.IntersectionTest", "MeshTest.SimpleMeshTest", "ImageIOTest.EncodeDecodeTest"):
+    for name in ("AABBTest.IntersectionTest", "MeshTest.SimpleMeshTest", "ImageIOTest.EncodeDecodeTest"):
         assert "[       OK ] " + name in r.stdout, r.stdout
 
 
@@ -67,7 +67,7 @@ def test_reference_sources_compile_unchanged():
 def test_api_program_on_gpu(api_test_exe):
     r = _run(api_test_exe)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("[       OK ]") == 8, r.stdout
+    assert r.stdout.count("[       OK ]") == 9, r.stdout
 
 
 @pytest.mark.gpu

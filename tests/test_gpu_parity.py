@@ -5,7 +5,7 @@ import pytest
 
 import oracle
 from cpupathtrace_amd import binding, scenes
-from tests.cases import golden, golden_mesh, opt_from, scene_set
+from tests.cases import golden, golden_mesh, opt_from, post_cases, scene_set
 from tests.util import assert_bits_equal, miss_equal
 
 pytestmark = pytest.mark.gpu
@@ -231,3 +231,20 @@ def test_edge_cases(gpu_scenes, sset):
     # rectangle outside the image is refused
     with pytest.raises(binding.PtError):
         sc.process_item(cam, scenes.options(8, 8, 1, 1), _tile_stream(4, 4, 8, 8, 5))
+
+
+def test_post_processing_golden():
+    """Device toneMap / gammaCorrect / postProcess (pt_post.hip) against the frames the compiled reference produced."""
+    for img, steps, gamma, want, label in post_cases():
+        assert_bits_equal(binding.post_process(img, steps, gamma), want, label)
+
+
+def test_post_processing_full_frame(gpu_scenes, sset, oracle_lib):
+    """A rendered 1024 x 1024 frame (BASELINE.json's size) through postProcess on the device and through the CPU oracle."""
+    cam = dict(sset["cornell"][1], aspect_ratio=-1.0)
+    frame = gpu_scenes("cornell").process_job(cam, scenes.options(1024, 1024, 2, 2), base_seed=1234)
+    for steps, gamma in ((1, 1.8), (2, 2.2), (3, 1.8)):
+        assert_bits_equal(binding.post_process(frame, steps, gamma), oracle_lib.post_process(frame, steps, gamma), "1024x1024 steps %d" % steps)
+    # idempotence-like property at full size: gamma 1 leaves the frame as it is (reference test/post_processing_test.cpp:36-46)
+    lit = frame[..., :3].max(axis=2) > 0
+    assert_bits_equal(binding.post_process(frame, 2, 1.0)[lit], frame[lit], "gamma 1")

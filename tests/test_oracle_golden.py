@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from tests.cases import CAMERAS, golden, golden_mesh, opt_from, scene_set
+from tests.cases import CAMERAS, golden, golden_mesh, opt_from, post_cases, scene_set
 from tests.util import assert_bits_equal, miss_equal
 
 SCENES = ["box", "cornell", "advanced", "simple", "meshbox", "cornellmesh"]
@@ -171,3 +171,13 @@ def test_tile_box_256spp(oracle_lib, sset):
     assert_bits_equal(tile, g["box_128_256"], "box tile")
     assert_bits_equal(st, g["box_state"], "box state")
     assert np.all(g["box_128_256"][7, 5] == np.float32([0.0112971449, 0.0112971449, 0.0112971449, 1.0]))
+
+
+def test_post_processing(oracle_lib):
+    """toneMap / gammaCorrect / postProcess of the reference (tests/golden/post.npz) -- SURVEY.md 8(f) rank 3.  Black pixels become
+    NaN under gammaCorrect in the reference too (0 * powf(0, negative)); NaNs must sit in the same places."""
+    n = 0
+    for img, steps, gamma, want, label in post_cases():
+        assert_bits_equal(oracle_lib.post_process(img, steps, gamma), want, label)
+        n += 1
+    assert n == 4 * 6

@@ -171,3 +171,12 @@ def test_host_library_scene_helpers_match_reference(ref_lib):
             assert res[0][0] == res[1][0]
             assert_bits_equal(res[0][1], res[1][1], name)
             assert_bits_equal(res[0][2], res[1][2], name + " normals")
+
+
+def test_post_processing_fresh_inputs(ref_lib, oracle_lib):
+    rng = np.random.default_rng(808)
+    for h, w in ((64, 96), (31, 33), (1, 1), (2, 700)):
+        img = np.exp(rng.normal(-2.0, 3.0, (h, w, 4))).astype(F)
+        img[..., 3] = rng.integers(0, 2, (h, w)).astype(F) if h > 1 else 1.0
+        for steps, gamma in ((1, 1.8), (2, 1.8), (2, 2.2), (2, 0.45), (3, 1.8)):
+            assert_bits_equal(oracle_lib.post_process(img, steps, gamma), ref_lib.post_process(img, steps, gamma), "post %dx%d steps %d gamma %g" % (w, h, steps, gamma))

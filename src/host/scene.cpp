@@ -4,12 +4,15 @@
 #include "../../include/pt_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <map>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <typeinfo>
 
 namespace {
 
@@ -63,36 +66,103 @@ namespace {
 
 Scene::Scene(std::vector<std::unique_ptr<Object>> &&objs, std::vector<std::unique_ptr<LightSource>> &&lights) :
   objects(std::move(objs)), light_sources(std::move(lights)) {
-    std::vector<uint8_t> kinds;
+    std::vector<uint8_t> kinds(objects.size());
     std::vector<float> tri_pos, tri_nrm, spheres, light_pos, light_spectrum;
     std::vector<uint8_t> tri_cull;
     std::vector<uint32_t> tri_material, sphere_material;
     std::vector<pt_material> materials;
     std::map<const MaterialHandler *, uint32_t> known;
-    kinds.reserve(objects.size());
 
-    for(const auto &object : objects) {
-        const uint32_t material = materialIndex(object->getMaterialHandler(), known, materials);
-        if(const auto *t = dynamic_cast<const Triangle *>(object.get())) {
-            kinds.push_back(PT_OBJ_TRIANGLE);
-            for(const vec3<float> *v : {&t->a, &t->b, &t->c}) {
-                tri_pos.insert(tri_pos.end(), {(*v)[0], (*v)[1], (*v)[2]});
+    auto onAllCores = [](size_t count, auto body) { // body(first, last) over contiguous slices of [0, count)
+        const size_t workers = count < 65536 ? 1 : std::min<size_t>(std::max(1U, std::thread::hardware_concurrency()), 64);
+        if(workers == 1) {
+            body(size_t{0}, count);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for(size_t w = 0; w < workers; w++) {
+            pool.emplace_back(body, count * w / workers, count * (w + 1) / workers);
+        }
+        for(auto &worker : pool) {
+            worker.join();
+        }
+    };
+
+    // pass 1, on all cores (the objects are scattered over the heap): dynamic type and material handler of every object
+    std::vector<const MaterialHandler *> handler_of(objects.size());
+    std::atomic<bool> unknown_kind{false};
+    onAllCores(objects.size(), [&](size_t first, size_t last) {
+        for(size_t i = first; i < last; i++) {
+            const Object &object = *objects[i];
+            handler_of[i] = object.getMaterialHandler();
+            if(typeid(object) == typeid(Triangle)) { // both classes are final: the dynamic type is the class itself or something else
+                kinds[i] = PT_OBJ_TRIANGLE;
             }
-            for(const vec3<float> *v : {&t->normal_a, &t->normal_b, &t->normal_c}) {
-                tri_nrm.insert(tri_nrm.end(), {(*v)[0], (*v)[1], (*v)[2]});
+            else if(typeid(object) == typeid(Sphere)) {
+                kinds[i] = PT_OBJ_SPHERE;
             }
-            tri_cull.push_back(t->cullsBackface() ? 1 : 0);
-            tri_material.push_back(material);
+            else {
+                unknown_kind.store(true);
+            }
         }
-        else if(const auto *s = dynamic_cast<const Sphere *>(object.get())) {
-            kinds.push_back(PT_OBJ_SPHERE);
-            const auto o = s->getOrigin();
-            spheres.insert(spheres.end(), {o[0], o[1], o[2], s->getRadius()});
-            sphere_material.push_back(material);
+    });
+    if(unknown_kind.load()) {
+        throw std::invalid_argument("PathTrace: only Triangle and Sphere objects can be rendered on the device");
+    }
+    // ... then, in order, its position among the objects of its kind and its material index (meshes share one handler, so the
+    // last one seen is remembered before the map is asked)
+    std::vector<uint32_t> typed_index(objects.size()), material_of(objects.size());
+    uint32_t n_triangles = 0, n_spheres = 0;
+    {
+        const MaterialHandler *last_handler = nullptr;
+        uint32_t last_material = 0;
+        bool have_last = false;
+        for(size_t i = 0; i < objects.size(); i++) {
+            if(!have_last || handler_of[i] != last_handler) {
+                last_material = materialIndex(handler_of[i], known, materials);
+                last_handler = handler_of[i];
+                have_last = true;
+            }
+            material_of[i] = last_material;
+            typed_index[i] = kinds[i] == PT_OBJ_TRIANGLE ? n_triangles++ : n_spheres++;
         }
-        else {
-            throw std::invalid_argument("PathTrace: only Triangle and Sphere objects can be rendered on the device");
-        }
+    }
+    // pass 2, on all cores: the coordinate arrays
+    tri_pos.resize(9 * static_cast<size_t>(n_triangles));
+    tri_nrm.resize(9 * static_cast<size_t>(n_triangles));
+    tri_cull.resize(n_triangles);
+    tri_material.resize(n_triangles);
+    spheres.resize(4 * static_cast<size_t>(n_spheres));
+    sphere_material.resize(n_spheres);
+    {
+        auto fill = [&](size_t first, size_t last) {
+            for(size_t i = first; i < last; i++) {
+                const size_t k = typed_index[i];
+                if(kinds[i] == PT_OBJ_TRIANGLE) {
+                    const auto *t = static_cast<const Triangle *>(objects[i].get());
+                    const vec3<float> *points[3] = {&t->a, &t->b, &t->c};
+                    const vec3<float> *normals[3] = {&t->normal_a, &t->normal_b, &t->normal_c};
+                    for(int v = 0; v < 3; v++) {
+                        for(int c = 0; c < 3; c++) {
+                            tri_pos[9 * k + 3 * static_cast<size_t>(v) + static_cast<size_t>(c)] = (*points[v])[static_cast<size_t>(c)];
+                            tri_nrm[9 * k + 3 * static_cast<size_t>(v) + static_cast<size_t>(c)] = (*normals[v])[static_cast<size_t>(c)];
+                        }
+                    }
+                    tri_cull[k] = t->cullsBackface() ? 1 : 0;
+                    tri_material[k] = material_of[i];
+                }
+                else {
+                    const auto *sphere = static_cast<const Sphere *>(objects[i].get());
+                    const auto o = sphere->getOrigin();
+                    spheres[4 * k + 0] = o[0];
+                    spheres[4 * k + 1] = o[1];
+                    spheres[4 * k + 2] = o[2];
+                    spheres[4 * k + 3] = sphere->getRadius();
+                    sphere_material[k] = material_of[i];
+                }
+            }
+        };
+        onAllCores(objects.size(), fill);
     }
     for(const auto &light : light_sources) {
         const auto *point = dynamic_cast<const PointLightSource *>(light.get());

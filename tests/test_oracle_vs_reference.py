@@ -3,6 +3,7 @@ the C oracle on fresh random inputs (larger than the committed fixtures), the nu
 cpupathtrace_amd.scenes, and the host-side scene-construction helpers of libPathTrace.so (makePlane, makeBox, mat4, OBJ
 loader) -- all bit for bit."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -156,6 +157,59 @@ def test_host_library_scene_helpers_match_reference(ref_lib):
         assert outs[0][0] == outs[1][0] and outs[0][0] > 1000
         assert_bits_equal(outs[0][1], outs[1][1], "OBJ positions")
         assert_bits_equal(outs[0][2], outs[1][2], "OBJ normals (smooth=%d)" % smooth)
+    # the loader reads pieces of the text concurrently and falls back to one piece when a line's numbers spill over a line end:
+    # tiny pieces over well-formed and malformed text, against the reference's sequential reader
+    os.environ["PATHTRACE_LOADER_PIECE_BYTES"] = "48"
+    try:
+        for case in range(12):
+            text = _obj_text(rng, 120, 400)
+            if case % 3 == 1:   # a vertex line one number short: its third number is taken from the next line
+                text = text.replace("\nv ", "\nv 0.25 1.5\nv ", 3)
+            elif case % 3 == 2:  # a face line that continues on the next line, a lone sign, an exponent without digits, a huge index
+                text = text.replace("\nf ", "\nf 3 4\n5\nf ", 2) + "\nv 1e 2 -\nv 1 2 3\nf 99999999999 1 2\nf 1 2 3"
+            data = text.encode()
+            outs = []
+            for lib, prefix in ((host, "pth_"), (ref, "ref_")):
+                pos, nrm = np.zeros((cap, 9), F), np.zeros((cap, 9), F)
+                n = getattr(lib, prefix + "load_mesh")(C.c_char_p(data), C.c_uint64(len(data)), C.c_void_p(m.ctypes.data), C.c_int(case & 1), C.c_uint64(cap),
+                                                       C.c_void_p(pos.ctypes.data), C.c_void_p(nrm.ctypes.data))
+                outs.append((n, pos[:n].copy(), nrm[:n].copy()))
+            assert outs[0][0] == outs[1][0], (case, outs[0][0], outs[1][0])
+            assert_bits_equal(outs[0][1], outs[1][1], "OBJ positions, pieces, case %d" % case)
+            assert_bits_equal(outs[0][2], outs[1][2], "OBJ normals, pieces, case %d" % case)
+    finally:
+        del os.environ["PATHTRACE_LOADER_PIECE_BYTES"]
+    # number reading: decimals of up to 17 digits (the loader converts short plain decimals itself and leaves the rest, and every
+    # value close to the midpoint of two floats, to strtof), against the reference's std::stof
+    n_vertices = 60000
+    digits = rng.integers(1, 18, (n_vertices, 3))
+    lines = []
+    for row in digits:
+        words = []
+        for d in row:
+            whole = int(rng.integers(0, 4))
+            word = "".join(str(int(c)) for c in rng.integers(0, 10, d))
+            word = (word[:whole] or "0") + "." + word[whole:] if rng.integers(0, 8) else word[:9]
+            words.append(("-" if rng.integers(0, 2) else "") + word)
+        lines.append("v " + " ".join(words))
+    # values sitting (almost) exactly between two floats
+    for k in range(2000):
+        base = np.float32(rng.uniform(0.001, 1000.0))
+        mid = (np.float64(base) + np.float64(np.nextafter(base, np.float32(np.inf)))) / 2
+        lines.append("v %.13f %.14f %.12f" % (mid, mid, mid))
+    n_vertices += 2000
+    lines += ["f %d %d %d" % (i + 1, i + 2, i + 3) for i in range(0, n_vertices - 2, 3)]
+    data = "\n".join(lines).encode()
+    big = 30000
+    ident = np.eye(4, dtype=F)
+    outs = []
+    for lib, prefix in ((host, "pth_"), (ref, "ref_")):
+        pos, nrm = np.zeros((big, 9), F), np.zeros((big, 9), F)
+        n = getattr(lib, prefix + "load_mesh")(C.c_char_p(data), C.c_uint64(len(data)), C.c_void_p(ident.ctypes.data), C.c_int(0), C.c_uint64(big),
+                                               C.c_void_p(pos.ctypes.data), C.c_void_p(nrm.ctypes.data))
+        outs.append((n, pos[:n].copy()))
+    assert outs[0][0] == outs[1][0] and outs[0][0] > 15000
+    assert_bits_equal(outs[0][1], outs[1][1], "decimal -> float")
     for _ in range(20):
         a, b = rng.uniform(-3, 3, 3).astype(F), rng.uniform(-3, 3, 3).astype(F)
         k = rng.integers(0, 3)

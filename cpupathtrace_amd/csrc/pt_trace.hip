@@ -264,7 +264,9 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                         inv = slab_inverse(d);
                         best_ref = PT_REF_NONE;
                         best_t = -1.0f;
-                        t_max = FLT_MAX;
+                        // a shadow ray only asks for a hit nearer than the light: nothing that is entered at or beyond that
+                        // distance can hold one, so the walk starts with the threshold as its pruning distance
+                        t_max = (dest & PT_DEST_SHADOW) ? thr : FLT_MAX;
                         sp = 0;
                         active = true;
                         if(COUNT) {

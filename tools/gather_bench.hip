@@ -71,9 +71,10 @@ __global__ __launch_bounds__(256) void gather(const f4v *__restrict__ table, uin
 }
 
 int main(int argc, char **argv) {
-    const size_t mb = argc > 1 ? atol(argv[1]) : 461;
+    const size_t kb = argc > 1 ? atol(argv[1]) : 461 * 1024; // table size in KiB
+    const size_t mb = kb / 1024;
     const int steps = argc > 2 ? atoi(argv[2]) : 64;
-    const uint32_t n_records = (uint32_t)(mb * 1024 * 1024 / 64);
+    const uint32_t n_records = (uint32_t)(kb * 1024 / 64);
     f4v *table;
     float *out;
     hipMalloc(&table, (size_t)n_records * 64);
@@ -98,7 +99,7 @@ int main(int argc, char **argv) {
                 if(ms < best) best = ms;
             }
             const double recs = (double)grid * 256 * steps;
-            printf("table %zu MB  blocks/CU %d  variant %d: %.3f ms  %.1f Grec/s  %.0f GB/s (64 B/record)  %.0f ns per dependent step\n", mb, blocks_per_cu, variant, best,
+            printf("table %zu KiB (%zu MB)  blocks/CU %d  variant %d: %.3f ms  %.1f Grec/s  %.0f GB/s (64 B/record)  %.0f ns per dependent step\n", kb, mb, blocks_per_cu, variant, best,
                    recs / best / 1e6, recs * 64 / best / 1e6, best * 1e6 / steps);
         }
         hipFree(out);

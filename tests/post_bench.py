@@ -1,4 +1,5 @@
-"""Times postProcess on a rendered frame: device (HBM-resident, pt_post_process_device), device with host buffers (pt_post_process),
+"""(Run as a script on the GPU box: python tests/post_bench.py [size]; it lives under tests/ because it uses the CPU checker.)
+Times postProcess on a rendered frame: device (HBM-resident, pt_post_process_device), device with host buffers (pt_post_process),
 and the CPU checker (compiled reference if oracle/_ref is present, else the C restatement)."""
 import ctypes as C
 import os, sys, time

@@ -7,9 +7,9 @@ Metric (BASELINE.json / reference benchmark/main.cpp:20,30): Msamples/s = image_
 of processJob with min_sample_count == max_sample_count == spp; one sample = one camera path with all its bounces and
 shadow rays.  A "step" is one whole processJob of the workload's frame.  Default workload (N = 1): the benchmark's
 DragonBox scene (benchmark/main.cpp:59-105) with the procedural 7.2 M-triangle stand-in for assets/xyzrgb_dragon.obj
-(absent from the reference mount), 1024 x 1024.  For N > 1 the frame grows with N (1024 * a x 1024 * b, a * b = N): every
-GPU renders 1 Mpixel of interleaved 32x32 tiles ("weak" scaling), the scene is replicated, and the tiles are gathered
-to rank 0 over RCCL at the end of every step.  Inputs are synthetic (procedural mesh), resident in HBM before the timed
+(absent from the reference mount), 1024 x 1024.  For N > 1 the same view is rendered at sqrt(N) times the resolution per side
+(1448, 2048, 2896 pixels for 2, 4, 8 GPUs): every GPU renders 1 Mpixel of interleaved 32x32 tiles with the same per-pixel work
+("weak" scaling), the scene is replicated, and the tiles are gathered to rank 0 over RCCL at the end of every step.  Inputs are synthetic (procedural mesh), resident in HBM before the timed
 region; scene build/upload is reported separately.
 
 Prints ONE JSON line on rank 0.
@@ -55,11 +55,11 @@ class heartbeat:
 
 
 def frame_for(n_gpus, base):
-    a = 1
-    while a * a < n_gpus:
-        a *= 2
-    b = max(n_gpus // a, 1)
-    return base * a, base * b
+    """Weak scaling with the VIEW kept: N GPUs render the same square view at sqrt(N) times the resolution per side (rounded down to a
+    multiple of 8), i.e. N x base^2 pixels of the same statistics -- 1024, 1448, 2048, 2896 for 1, 2, 4, 8 GPUs.  (Widening the frame
+    instead would add background pixels, whose paths end at once: more pixels but less work per pixel.)"""
+    side = int(base * (n_gpus ** 0.5) + 1e-9) // 8 * 8
+    return side, side
 
 
 def build_workload(name, width, height, mesh_n):
@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dragon")
-    ap.add_argument("--size", type=int, default=1024, help="pixels per side per GPU")
+    ap.add_argument("--size", type=int, default=1024, help="pixels per side at one GPU (N GPUs: sqrt(N) times as many)")
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--mesh-n", type=int, default=1900, help="stand-in mesh resolution (nu = nv); 1900 -> 7.2 M triangles")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")

@@ -12,7 +12,7 @@
 //   * the objects of every node are a contiguous range of four arrays of object indices: `ord` (input order) and `srt[k]` (sorted
 //     by the low coordinate on axis k; three radix sorts once, up front).  A stable partition of a sorted list stays sorted, so the
 //     median of step 1 is ONE LOOKUP per node and axis;
-//   * step 2: ranges of up to 32 objects are reduced by one thread; longer ones by all their objects in parallel through
+//   * step 2: ranges of up to 128 objects are reduced by one thread; longer ones by all their objects in parallel through
 //     order-preserving integer keys and atomic min/max (wave-aggregated when a wavefront lies inside one range: the top levels);
 //   * steps 4 and 5 are one exclusive scan of the "goes left" flags over `ord` (new position = range start + rank, the moved tail
 //     of step 5 is appended to the right range in reverse order) and one 3-wide scan for the three sorted lists;
@@ -35,7 +35,7 @@
 namespace {
 
 constexpr uint32_t NONE = 0xffffffffu;
-constexpr uint32_t SMALL = 32; // ranges up to this many objects are reduced by a single thread
+constexpr uint32_t SMALL = 128; // ranges up to this many objects are reduced by a single thread
 
 __device__ __forceinline__ float fmin_std(float a, float b) {
     return (b < a) ? b : a;

@@ -248,3 +248,37 @@ def test_post_processing_full_frame(gpu_scenes, sset, oracle_lib):
     # idempotence-like property at full size: gamma 1 leaves the frame as it is (reference test/post_processing_test.cpp:36-46)
     lit = frame[..., :3].max(axis=2) > 0
     assert_bits_equal(binding.post_process(frame, 2, 1.0)[lit], frame[lit], "gamma 1")
+
+
+@pytest.mark.parametrize("which,spp_min,spp_max", [("cornell", 16, 16), ("mesh80k", 8, 8), ("cornell_adaptive", 4, 24)])
+def test_full_size_frame_sampled_against_oracle(sset, oracle_lib, which, spp_min, spp_max):
+    """BASELINE.json's frame size (1024 x 1024, one stream per pixel = 1 M streams in flight, suspended walks, sample overlap, two stream
+    groups for the LDS-resident scene) checked where the oracle can follow: 3000 random pixels rendered by the CPU oracle with the same
+    per-pixel engines must equal the frame's pixels bit for bit.  Also: the frame is reproducible, and the sum of its four quadrants
+    rendered as separate jobs (disjoint tile sets) reproduces it exactly."""
+    if which.startswith("cornell"):
+        desc, cam = sset["cornell"]
+        cam = dict(cam, aspect_ratio=-1.0)
+    else:
+        desc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(200, 200, scenes.DRAGON_BOX_TRANSFORM))
+    w = h = 1024
+    opt = scenes.options(w, h, spp_min, spp_max)
+    scene = binding.Scene(desc)
+    try:
+        frame = scene.process_job(cam, opt, base_seed=77)
+        rng = np.random.default_rng(5)
+        xs, ys = rng.integers(0, w, 3000).astype(np.int32), rng.integers(0, h, 3000).astype(np.int32)
+        states = np.array([binding.seed_to_state(binding.pixel_seed(77, int(x), int(y))) for x, y in zip(xs, ys)], np.uint64)
+        want, _ = oracle_lib.scene_create(desc).render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=16)
+        assert_bits_equal(frame[ys, xs], want[ys, xs], "sampled pixels of the full-size frame")
+        assert_bits_equal(scene.process_job(cam, opt, base_seed=77), frame, "same job twice")
+        tiles = binding.job_tiles(w, h)
+        parts = np.zeros_like(frame)
+        for qx in (0, 1):
+            for qy in (0, 1):
+                mine = tiles[(tiles["x"] // 512 == qx) & (tiles["y"] // 512 == qy)]
+                img = scene.process_job(cam, opt, base_seed=77, tiles=mine)
+                parts += img
+        assert_bits_equal(parts, frame, "four quadrant jobs add up to the frame")
+    finally:
+        scene.close()

@@ -250,7 +250,7 @@ def test_post_processing_full_frame(gpu_scenes, sset, oracle_lib):
     assert_bits_equal(binding.post_process(frame, 2, 1.0)[lit], frame[lit], "gamma 1")
 
 
-@pytest.mark.parametrize("which,spp_min,spp_max", [("cornell", 16, 16), ("mesh80k", 8, 8), ("cornell_adaptive", 4, 24)])
+@pytest.mark.parametrize("which,spp_min,spp_max", [("cornell", 16, 16), ("mesh80k", 8, 8), ("cornell_adaptive", 4, 24), ("mesh7m", 4, 4)])
 def test_full_size_frame_sampled_against_oracle(sset, oracle_lib, which, spp_min, spp_max):
     """BASELINE.json's frame size (1024 x 1024, one stream per pixel = 1 M streams in flight, suspended walks, sample overlap, two stream
     groups for the LDS-resident scene) checked where the oracle can follow: 3000 random pixels rendered by the CPU oracle with the same
@@ -260,7 +260,10 @@ def test_full_size_frame_sampled_against_oracle(sset, oracle_lib, which, spp_min
         desc, cam = sset["cornell"]
         cam = dict(cam, aspect_ratio=-1.0)
     else:
-        desc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(200, 200, scenes.DRAGON_BOX_TRANSFORM))
+        # mesh7m is bench.py's default workload itself: 7.2 M triangles, a 30-level tree built on the device, walks that outgrow the
+        # LDS window of the traversal stack and spill to HBM
+        side = 1900 if which == "mesh7m" else 200
+        desc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(side, side, scenes.DRAGON_BOX_TRANSFORM))
     w = h = 1024
     opt = scenes.options(w, h, spp_min, spp_max)
     scene = binding.Scene(desc)

@@ -17,23 +17,21 @@
 //
 // How it maps to gfx950:
 //   * one ray per lane, 256-thread workgroups, persistent: a wavefront refills its idle lanes from the queue whenever at least
-//     PT_REFILL_IDLE lanes are idle (ballot + popcount; lane i takes the i-th ray of the wave's reservation by
+//     `refill_idle` lanes are idle (ballot + popcount; lane i takes the i-th ray of the wave's reservation by
 //     prefix-popcount of the idle mask; one atomic reserves PT_QCHUNK rays), so lanes that drew short traversals do not
 //     wait for the longest one;
 //   * the queue has one shard per XCD: a workgroup drains shard blockIdx.x % 8 first (rays appended by shading workgroups
 //     of the same residue, i.e. neighbouring pixels share an L2), then steals from the others;
 //   * inner nodes are 64-byte records holding BOTH child boxes, so a traversal step is one 64-byte fetch (4 x dwordx4) per
-//     lane; the breadth-first top of the tree and, for small scenes, the triangle records are staged in LDS once per
-//     workgroup; everything else is a random HBM/L2 fetch -- the kernel is bound by memory latency/bandwidth, there is no
-//     matrix work in it (no MFMA);
+//     lane; scenes whose whole tree and triangle records fit in 24 KiB are staged in LDS once per workgroup (for larger ones an
+//     LDS copy of the top of the tree was measured and does not pay); everything else is a random L1/L2/HBM fetch -- the kernel
+//     is bound by dependent fetches executed in lockstep, there is no matrix work in it (no MFMA);
 //   * the traversal stack lives in LDS ([slot][lane] layout: conflict-free ds_read_b64/ds_write_b64) as a window over the
 //     top STACK_LDS entries, with older entries of unusually deep walks in a per-lane HBM spill area.
 #include "pt_device.h"
 #include "pt_kernels.h"
 
 using namespace ptd;
-
-#define PT_REFILL_IDLE 20 /* refill once this many of the 64 lanes are idle */
 
 namespace {
 

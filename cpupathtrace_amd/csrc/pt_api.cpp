@@ -150,7 +150,7 @@ struct pt_scene {
     std::vector<float> emissive_cdf;
 
     // device scene
-    DevBuf<F4> pairs, tris, tri_shade, spheres, materials, lights, emis;
+    DevBuf<F4> pairs, quads, tris, tri_shade, spheres, materials, lights, emis;
     DevBuf<uint2> sph_meta;
     DevBuf<float> emis_cdf;
     PtDevScene dev{};
@@ -345,7 +345,7 @@ int setup_trace(pt_scene *s) {
         stack_lds = 16;
     }
     cfg.stack_lds = stack_lds;
-    cfg.lds_mode = (s->dev.n_lds_pairs == 0 && s->dev.n_lds_tris == 0) ? 0 : ((s->dev.n_lds_pairs == s->dev.n_pairs && s->dev.n_lds_tris == s->dev.n_tris) ? 2 : 1);
+    cfg.lds_mode = (s->dev.n_lds_pairs == 0 && s->dev.n_lds_tris == 0) ? (s->dev.quads != nullptr ? 3 : 0) : ((s->dev.n_lds_pairs == s->dev.n_pairs && s->dev.n_lds_tris == s->dev.n_tris) ? 2 : 1);
     cfg.lds_bytes = static_cast<size_t>(stack_lds) * 256 * sizeof(uint2) + static_cast<size_t>(s->dev.n_lds_pairs) * 64 + static_cast<size_t>(s->dev.n_lds_tris) * 48;
     const int per_cu = pt_trace_blocks_per_cu(stack_lds, cfg.lds_mode, cfg.lds_bytes);
     const int limit = env_int("PT_TRACE_BLOCKS_PER_CU", 0);
@@ -784,6 +784,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
 
     std::vector<int32_t> dfs; // leaves depth-first, left to right (Scene::registerEmissiveObjects order); device path: only those with an emissive material
     uint32_t n_pairs = 0, root_ref = PT_REF_NONE;
+    std::vector<uint32_t> level_begin; // pair slots of the tree's levels (for the two-level records)
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
     if(use_device) {
         // ---- device: upload the caller's arrays as they are; records, leaf boxes and the tree are made in HBM ----------------------
@@ -850,6 +851,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         }
         n_pairs = built.n_pairs;
         root_ref = built.root_ref;
+        level_begin = built.level_begin;
         for(int k = 0; k < 3; k++) {
             root_lo[k] = built.root_lo[k];
             root_hi[k] = built.root_hi[k];
@@ -918,6 +920,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         ptb::FlatBvh flat = ptb::flatten_breadth_first(s->tree, leaf_ref, align_siblings);
         n_pairs = flat.n_pairs;
         root_ref = flat.root_ref;
+        level_begin = flat.level_begin;
         for(int k = 0; k < 3; k++) {
             root_lo[k] = flat.root_box.lo[k];
             root_hi[k] = flat.root_box.hi[k];
@@ -1093,6 +1096,19 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     else {
         dev.n_lds_pairs = std::min(n_pairs, static_cast<uint32_t>(std::max(env_int("PT_LDS_PAIRS", 0), 0)));
         dev.n_lds_tris = 0;
+    }
+
+    dev.quads = nullptr;
+    dev.n_quads = 0;
+    if(dev.n_lds_pairs == 0 && n_pairs > 0 && (root_ref & PT_REF_LEAF) == 0 && env_int("PT_WIDE", 0) != 0) {
+        // HBM-resident tree: two-level records, one dependent fetch per two levels of a walk (pt_trace.hip, LDS_MODE 3)
+        float4 *quads = nullptr;
+        uint32_t n_quads = 0;
+        PT_HIP(pt_build_quads(s->stream, reinterpret_cast<const float4 *>(s->pairs.ptr), level_begin, &quads, &n_quads));
+        s->quads.ptr = reinterpret_cast<F4 *>(quads);
+        s->quads.count = 12 * static_cast<size_t>(n_quads);
+        dev.quads = quads;
+        dev.n_quads = n_quads;
     }
 
     int rc = setup_trace(s.get());

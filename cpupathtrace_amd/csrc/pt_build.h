@@ -38,11 +38,17 @@ struct PtBuildOutput {
     float root_lo[3] = {0, 0, 0};
     float root_hi[3] = {0, 0, 0};
     float build_ms = 0.0F; // device time of the tree construction (HIP events), records excluded
+    std::vector<uint32_t> level_begin; // first pair slot of every level of inner nodes, plus the end of the last level
 };
 
 // Returns hipSuccess or the first HIP error; `error_text` (optional) receives a static description of the failing step.
 // Requires n_objects >= 2.
 hipError_t pt_build_scene_device(hipStream_t stream, const PtBuildInput &in, PtBuildOutput &out, const char **error_text);
+
+// Two-level records for the traversal of HBM-resident trees (pt_types.h: quads): for every inner node of an EVEN level a 192-byte
+// record = its own pair record followed by the pair records of its two children (zeros where a child is a leaf), with the
+// grandchildren's references rewritten to record indices.  `quads_out` is hipMalloc'ed; ownership passes to the caller.
+hipError_t pt_build_quads(hipStream_t stream, const float4 *pairs, const std::vector<uint32_t> &level_begin, float4 **quads_out, uint32_t *n_quads_out);
 
 // Positions of the objects whose bit is set in `mask_bits` (host array, one bit per object) within the depth-first leaf order
 // `dfs` (device).  On return `ordered` lists those objects in depth-first order.

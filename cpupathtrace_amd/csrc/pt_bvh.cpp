@@ -233,7 +233,13 @@ FlatBvh flatten_breadth_first(const Tree &tree, const std::vector<uint32_t> &lea
     std::vector<uint32_t> pair_index(tree.nodes.size(), 0xffffffffu);
     order.push_back(tree.root);
     pair_index[tree.root] = 0;
+    size_t level_end = 1; // the root is level 0
+    flat.level_begin.push_back(0U);
     for(size_t head = 0; head < order.size(); head++) {
+        if(head == level_end) {
+            flat.level_begin.push_back(static_cast<uint32_t>(head));
+            level_end = order.size();
+        }
         if(order[head] < 0) {
             continue;
         }
@@ -252,6 +258,7 @@ FlatBvh flatten_breadth_first(const Tree &tree, const std::vector<uint32_t> &lea
     }
 
     flat.n_pairs = static_cast<uint32_t>(order.size());
+    flat.level_begin.push_back(flat.n_pairs);
     flat.root_ref = 0;
     flat.pairs.assign(16 * order.size(), 0.0F);
     auto ref_of = [&](int32_t node) -> uint32_t {

@@ -43,6 +43,7 @@ struct FlatBvh {
     uint32_t n_pairs = 0;
     uint32_t root_ref = 0xffffffffu;
     Box root_box{};
+    std::vector<uint32_t> level_begin; // first pair slot of every level of inner nodes, plus the end of the last level
 };
 
 // leaf_ref[i] = reference word of object i (PT_REF_LEAF | kind bit | typed index)

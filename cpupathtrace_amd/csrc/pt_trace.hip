@@ -69,7 +69,8 @@ PT_D float slab_walk(V3 lo, V3 hi, V3 o, V3 inv) {
 
 // LDS_MODE: 0 = every node/triangle record comes from HBM/L2 (large scenes: the LDS copy only costs occupancy),
 //           1 = records with index < n_lds_* come from LDS, the rest from HBM (breadth-first top of the tree),
-//           2 = the whole tree and all triangles are in LDS (small scenes).
+//           2 = the whole tree and all triangles are in LDS (small scenes),
+//           3 = as 0, but the walk reads the two-level records (sc.quads): two levels of the tree per dependent fetch.
 template<int STACK_LDS, int LDS_MODE, bool COUNT>
 __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q, PtCarry carry, int parity, int max_steps, int drain_lanes, int chunk, int burst_steps,
                                                        uint2 *__restrict__ hit,
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
-    if(LDS_MODE != 0) {
+    if(LDS_MODE == 1 || LDS_MODE == 2) {
         // stage the top of the tree (and the triangles of small scenes) in LDS
         for(uint32_t i = tid; i < 4 * sc.n_lds_pairs; i += 256) {
             lds_pairs[i] = sc.pairs[i];
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
     lds_f4_cptr tris_l = (lds_f4_cptr)lds_tris;
     glb_f4_cptr pairs_g = (glb_f4_cptr)sc.pairs;
     glb_f4_cptr tris_g = (glb_f4_cptr)sc.tris;
+    glb_f4_cptr quads_g = (glb_f4_cptr)sc.quads;
 
     // The traversal stack: the top STACK_LDS entries of a lane live in LDS (slot = index mod STACK_LDS), older ones in the
     // lane's HBM spill area.  Pushing onto a full window first moves the entry that is about to be overwritten to HBM;
@@ -300,7 +302,73 @@ __global__ __launch_bounds__(256) void pt_trace_kernel(PtDevScene sc, PtQueue q,
                 break;
             }
             w_steps++;
-            if(on_inner) {
+            if(LDS_MODE == 3) {
+                if(on_inner) {
+                    // Two levels per fetch: the record of an even-level node carries its children's pair records, so the walk
+                    // learns the entry distances of the node's two children AND of its (up to) four grandchildren from one
+                    // dependent access.  The visit order is still the recursion's: close child before far child, within each the
+                    // close grandchild first; a leaf child stands for itself.  Everything that is not entered right away is
+                    // parked with its entry distance and re-tested against the then-current t_max when it is popped -- for a
+                    // grandchild that test implies its parent's (a box inside a box is entered no earlier), which is the test
+                    // the recursion makes when it comes back to the far child (scene.cpp:129-137).
+                    glb_f4_cptr p = quads_g + 12 * (size_t)cur;
+                    const float4 a0 = to_f4(p[0]), a1 = to_f4(p[1]), a2 = to_f4(p[2]), a3 = to_f4(p[3]);
+                    const float4 l0 = to_f4(p[4]), l1 = to_f4(p[5]), l2 = to_f4(p[6]), l3 = to_f4(p[7]);
+                    const float4 r0 = to_f4(p[8]), r1 = to_f4(p[9]), r2 = to_f4(p[10]), r3 = to_f4(p[11]);
+                    const float t_l = slab_walk(v3(a0.x, a0.y, a0.z), v3(a0.w, a1.x, a1.y), o, inv);
+                    const float t_r = slab_walk(v3(a1.z, a1.w, a2.x), v3(a2.y, a2.z, a2.w), o, inv);
+                    const uint32_t ref_l = __float_as_uint(a3.x), ref_r = __float_as_uint(a3.y);
+                    const float t_ll = slab_walk(v3(l0.x, l0.y, l0.z), v3(l0.w, l1.x, l1.y), o, inv);
+                    const float t_lr = slab_walk(v3(l1.z, l1.w, l2.x), v3(l2.y, l2.z, l2.w), o, inv);
+                    const float t_rl = slab_walk(v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y), o, inv);
+                    const float t_rr = slab_walk(v3(r1.z, r1.w, r2.x), v3(r2.y, r2.z, r2.w), o, inv);
+                    // per side: first and second candidate in visit order (a leaf child is its own single candidate)
+                    const bool l_leaf = (ref_l & PT_REF_LEAF) != 0, r_leaf = (ref_r & PT_REF_LEAF) != 0;
+                    const bool ll_close = t_ll < t_lr, rl_close = t_rl < t_rr;
+                    const uint32_t l_first_ref = l_leaf ? ref_l : __float_as_uint(ll_close ? l3.x : l3.y);
+                    const float l_first_t = l_leaf ? t_l : (ll_close ? t_ll : t_lr);
+                    const uint32_t l_second_ref = __float_as_uint(ll_close ? l3.y : l3.x);
+                    const float l_second_t = l_leaf ? -1.0f : (ll_close ? t_lr : t_ll);
+                    const uint32_t r_first_ref = r_leaf ? ref_r : __float_as_uint(rl_close ? r3.x : r3.y);
+                    const float r_first_t = r_leaf ? t_r : (rl_close ? t_rl : t_rr);
+                    const uint32_t r_second_ref = __float_as_uint(rl_close ? r3.y : r3.x);
+                    const float r_second_t = r_leaf ? -1.0f : (rl_close ? t_rr : t_rl);
+                    const bool ok_l = t_l >= 0.0f && t_l < t_max, ok_r = t_r >= 0.0f && t_r < t_max;
+                    const bool left_close = t_l < t_r; // equal entry distances: right is "close" (scene.cpp:120-121)
+                    // candidates c0..c3 in visit order
+                    const bool ok_a = left_close ? ok_l : ok_r, ok_b = left_close ? ok_r : ok_l;
+                    const uint32_t c0_ref = left_close ? l_first_ref : r_first_ref, c1_ref = left_close ? l_second_ref : r_second_ref;
+                    const uint32_t c2_ref = left_close ? r_first_ref : l_first_ref, c3_ref = left_close ? r_second_ref : l_second_ref;
+                    const float c0_t = left_close ? l_first_t : r_first_t, c1_t = left_close ? l_second_t : r_second_t;
+                    const float c2_t = left_close ? r_first_t : l_first_t, c3_t = left_close ? r_second_t : l_second_t;
+                    const bool v0 = ok_a && c0_t >= 0.0f && c0_t < t_max, v1 = ok_a && c1_t >= 0.0f && c1_t < t_max;
+                    const bool v2 = ok_b && c2_t >= 0.0f && c2_t < t_max, v3_ = ok_b && c3_t >= 0.0f && c3_t < t_max;
+                    if(COUNT) {
+                        // binary-equivalent node visits: this node and each inner child that was entered
+                        n_nodes += 1u + ((ok_l && !l_leaf) ? 1u : 0u) + ((ok_r && !r_leaf) ? 1u : 0u);
+                    }
+                    if(v3_ && (v0 || v1 || v2)) {
+                        stack_push(sp, c3_ref, c3_t);
+                    }
+                    if(v2 && (v0 || v1)) {
+                        stack_push(sp, c2_ref, c2_t);
+                    }
+                    if(v1 && v0) {
+                        stack_push(sp, c1_ref, c1_t);
+                    }
+                    cur = v0 ? c0_ref : (v1 ? c1_ref : (v2 ? c2_ref : (v3_ ? c3_ref : PT_REF_NONE)));
+                    if(!(v0 || v1 || v2 || v3_)) {
+                        while(sp > 0) {
+                            const u2v e = stack_pop(sp);
+                            if(__uint_as_float(e.y) < t_max) {
+                                cur = e.x;
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+            else if(on_inner) {
                 float4 q0, q1, q2, q3;
                 if(LDS_MODE == 2 || (LDS_MODE == 1 && cur < sc.n_lds_pairs)) {
                     lds_f4_cptr p = pairs_l + 4 * cur;
@@ -505,6 +573,9 @@ void launch_trace_mode(hipStream_t stream, const PtDevScene &scene, PtQueue queu
         case 2:
             launch_trace<STACK_LDS, 2>(stream, scene, queue, carry, paths, cfg, counters);
             break;
+        case 3:
+            launch_trace<STACK_LDS, 3>(stream, scene, queue, carry, paths, cfg, counters);
+            break;
         default:
             launch_trace<STACK_LDS, 1>(stream, scene, queue, carry, paths, cfg, counters);
             break;
@@ -521,6 +592,9 @@ int occupancy_mode(int lds_mode, size_t lds_bytes) {
             break;
         case 2:
             err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<STACK_LDS, 2, true>, 256, lds_bytes);
+            break;
+        case 3:
+            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<STACK_LDS, 3, true>, 256, lds_bytes);
             break;
         default:
             err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_trace_kernel<STACK_LDS, 1, true>, 256, lds_bytes);

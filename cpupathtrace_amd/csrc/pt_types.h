@@ -8,6 +8,10 @@
 //                                     q1 = (L.hi.y, L.hi.z, R.lo.x, R.lo.y)
 //                                     q2 = (R.lo.z, R.hi.x, R.hi.y, R.hi.z)
 //                                     q3 = (bits L.ref, bits R.ref, 0, 0)
+//   quads     float4[12 * n_quads]  (scenes whose tree does not fit in LDS) one 192-byte record per inner node of an EVEN level:
+//                                   its own pair record, then the pair records of its left and right child (zeros for a leaf
+//                                   child); references to inner grandchildren are indices into this array.  One fetch serves
+//                                   two levels of the walk.
 //   tris      float4[3 * n_tris]    48-byte record per triangle for Moeller-Trumbore and the barycentric normal:
 //                                     q0 = (a.x, a.y, a.z, ab.x)  q1 = (ab.y, ab.z, ac.x, ac.y)  q2 = (ac.z, bits material, bits (obj | cull << 31), 0)
 //                                   ab = b - a and ac = c - a are the fp32 differences the reference forms on every call
@@ -61,6 +65,8 @@ struct PtDevScene {
     uint32_t n_object_samples; /* min(2 + int(log10(E + 1)), E), scene.cpp:226 */
     uint32_t n_lds_pairs;      /* pair records staged in LDS by the traversal kernel */
     uint32_t n_lds_tris;       /* triangle records staged in LDS */
+    const float4 *quads;       /* two-level records (12 float4 each) for HBM-resident trees, or null: see pt_trace.hip */
+    uint32_t n_quads;
 };
 
 // Derived camera state, Camera::Camera (src/camera.cpp:53-76)

@@ -285,3 +285,35 @@ def test_full_size_frame_sampled_against_oracle(sset, oracle_lib, which, spp_min
         assert_bits_equal(parts, frame, "four quadrant jobs add up to the frame")
     finally:
         scene.close()
+
+
+def test_two_level_walk_matches(sset, oracle_lib):
+    """PT_WIDE=1: the traversal reads two-level records (one fetch per two levels of the tree, pt_trace.hip LDS_MODE 3).  Same closest
+    hits and the same frame, bit for bit, as the default one-level walk and as the oracle."""
+    import os
+    desc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(120, 120, scenes.DRAGON_BOX_TRANSFORM))
+    old = os.environ.get("PT_WIDE")
+    os.environ["PT_WIDE"] = "1"
+    try:
+        wide = binding.Scene(desc)
+    finally:
+        if old is None:
+            del os.environ["PT_WIDE"]
+        else:
+            os.environ["PT_WIDE"] = old
+    plain = binding.Scene(desc)
+    try:
+        rng = np.random.default_rng(3)
+        d = rng.normal(size=(100000, 3))
+        rays = np.concatenate([rng.uniform(-1, 1, (100000, 3)), d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1).astype(np.float32)
+        (tw, ow), (tp, op) = wide.get_intersection(rays), plain.get_intersection(rays)
+        assert_bits_equal(tw, tp, "closest hit t")
+        assert_bits_equal(ow, op, "closest hit object")
+        to, oo = oracle_lib.scene_create(desc).intersect(rays)
+        miss_equal(tw, to, "closest hit t vs oracle")
+        assert_bits_equal(ow[to >= 0], oo[to >= 0], "object vs oracle")
+        opt = scenes.options(256, 256, 8, 8)
+        assert_bits_equal(wide.process_job(cam, opt, base_seed=9), plain.process_job(cam, opt, base_seed=9), "frame")
+    finally:
+        wide.close()
+        plain.close()

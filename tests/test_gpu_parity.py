@@ -317,3 +317,25 @@ def test_two_level_walk_matches(sset, oracle_lib):
     finally:
         wide.close()
         plain.close()
+
+
+@pytest.mark.parametrize("world,side", [(2, 362), (4, 512), (8, 724)])
+def test_frame_identical_for_any_gpu_count(gpu_scenes, sset, world, side):
+    """the assembled frame is bit-identical for 1, 2, 4, 8 ranks.  The ranks of a `world` are played one after the other
+    on this GPU with sharding.py's own tile split and gather indices (frame sides = bench.py's weak-scaling sides / 4)."""
+    from cpupathtrace_amd import sharding
+    cam = dict(sset["cornell"][1], aspect_ratio=-1.0)
+    opt = scenes.options(side, side, 4, 4)
+    sc = gpu_scenes("cornell")
+    full = sc.process_job(cam, opt, base_seed=21)
+    tiles = binding.job_tiles(side, side)
+    assembled = np.zeros_like(full).reshape(-1, 4)
+    covered = np.zeros(side * side, np.int32)
+    for rank in range(world):
+        mine = sharding.local_tiles(tiles, rank, world)
+        img = sc.process_job(cam, opt, base_seed=21, tiles=mine).reshape(-1, 4)
+        idx = sharding.pixel_indices(mine, side)
+        assembled[idx] = img[idx]      # what rank 0 does with the gathered chunk of this rank
+        covered[idx] += 1
+    assert (covered == 1).all(), "every pixel belongs to exactly one rank"
+    assert_bits_equal(assembled.reshape(full.shape), full, "frame assembled from %d ranks" % world)

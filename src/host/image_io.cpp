@@ -1,7 +1,8 @@
 // src/host/image_io.cpp -- PNG reading/writing for PathTrace/image/image_io.h, directly on zlib (no libpng in this image).
-// Writes 8-bit RGBA, filter 0, one IDAT; reads any non-interlaced 8-bit grey / grey+alpha / RGB / RGBA PNG.
+// Writes 8-bit RGBA, filter 0, one IDAT (row bands deflated in parallel); reads any non-interlaced 8-bit grey / grey+alpha / RGB / RGBA PNG.
 #include <PathTrace/image/image_io.h>
 
+#include <thread>
 #include <zlib.h>
 
 #include <algorithm>
@@ -54,23 +55,72 @@ namespace io {
         if(width <= 0 || height <= 0) {
             throw std::logic_error("writeRGBImage: empty image");
         }
-        std::vector<unsigned char> raw;
-        raw.reserve((static_cast<size_t>(width) * 4 + 1) * static_cast<size_t>(height));
-        for(int y = 0; y < height; y++) {
-            raw.push_back(0); // filter type: none
-            for(int x = 0; x < width; x++) {
-                const Color<float> c = image(x, y);
-                for(int k = 0; k < 4; k++) {
-                    raw.push_back(quantise(c[k]));
+        // The rows are cut into bands; every band is quantised and deflated on its own core (raw deflate, ended by a sync flush so
+        // that the pieces can simply be concatenated; the last one ends the stream) -- SURVEY.md 8(f) rank 4.  The result is one
+        // ordinary zlib stream: header, the bands, the Adler-32 of all the filtered bytes.
+        const size_t row_bytes = static_cast<size_t>(width) * 4 + 1;
+        const char *threads_env = std::getenv("PATHTRACE_PNG_THREADS");
+        const unsigned cores = threads_env != nullptr ? static_cast<unsigned>(std::max(1, std::atoi(threads_env))) : std::max(1U, std::thread::hardware_concurrency());
+        const size_t bands = std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(std::min(cores, 64U)), static_cast<size_t>(height) / 16 + 1,
+                                                                   row_bytes * static_cast<size_t>(height) / 65536 + 1}));
+        struct Band {
+            std::vector<unsigned char> packed;
+            uLong adler = 1; // adler32 of the band's filtered bytes
+            size_t raw_bytes = 0;
+            bool ok = false;
+        };
+        std::vector<Band> band(bands);
+        auto encode = [&](size_t b) {
+            const int first = static_cast<int>(static_cast<size_t>(height) * b / bands), last = static_cast<int>(static_cast<size_t>(height) * (b + 1) / bands);
+            std::vector<unsigned char> raw;
+            raw.reserve(row_bytes * static_cast<size_t>(last - first));
+            for(int y = first; y < last; y++) {
+                raw.push_back(0); // filter type: none
+                for(int x = 0; x < width; x++) {
+                    const Color<float> c = image(x, y);
+                    for(int k = 0; k < 4; k++) {
+                        raw.push_back(quantise(c[k]));
+                    }
                 }
             }
+            Band &out = band[b];
+            out.raw_bytes = raw.size();
+            out.adler = adler32(1L, raw.data(), static_cast<uInt>(raw.size()));
+            z_stream z{};
+            if(deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+                return;
+            }
+            out.packed.resize(deflateBound(&z, static_cast<uLong>(raw.size())) + 16);
+            z.next_in = raw.data();
+            z.avail_in = static_cast<uInt>(raw.size());
+            z.next_out = out.packed.data();
+            z.avail_out = static_cast<uInt>(out.packed.size());
+            const bool final_band = b + 1 == bands;
+            const int rc = deflate(&z, final_band ? Z_FINISH : Z_SYNC_FLUSH);
+            out.ok = final_band ? rc == Z_STREAM_END : (rc == Z_OK && z.avail_in == 0);
+            out.packed.resize(out.packed.size() - z.avail_out);
+            deflateEnd(&z);
+        };
+        {
+            std::vector<std::thread> pool;
+            for(size_t b = 1; b < bands; b++) {
+                pool.emplace_back(encode, b);
+            }
+            encode(0);
+            for(auto &t : pool) {
+                t.join();
+            }
         }
-        uLongf packed_size = compressBound(static_cast<uLong>(raw.size()));
-        std::vector<unsigned char> packed(packed_size);
-        if(compress2(packed.data(), &packed_size, raw.data(), static_cast<uLong>(raw.size()), 6) != Z_OK) {
-            throw std::logic_error("writeRGBImage: deflate failed");
+        std::vector<unsigned char> packed{0x78, 0x9C}; // zlib header: deflate, 32 KiB window, default level
+        uLong adler = 1;
+        for(size_t b = 0; b < bands; b++) {
+            if(!band[b].ok) {
+                throw std::logic_error("writeRGBImage: deflate failed");
+            }
+            packed.insert(packed.end(), band[b].packed.begin(), band[b].packed.end());
+            adler = b == 0 ? band[b].adler : adler32_combine(adler, band[b].adler, static_cast<z_off_t>(band[b].raw_bytes));
         }
-        packed.resize(packed_size);
+        put32(packed, static_cast<uint32_t>(adler));
 
         std::vector<unsigned char> file(kSignature, kSignature + 8);
         std::vector<unsigned char> header;

@@ -339,3 +339,32 @@ def test_frame_identical_for_any_gpu_count(gpu_scenes, sset, world, side):
         covered[idx] += 1
     assert (covered == 1).all(), "every pixel belongs to exactly one rank"
     assert_bits_equal(assembled.reshape(full.shape), full, "frame assembled from %d ranks" % world)
+
+
+@pytest.mark.parametrize("name,w,h,mn,mx,eps", [
+    ("advanced", 1, 1, 1, 1, 1e-3),         # a single pixel, a single sample
+    ("advanced", 3, 5, 0, 7, 1e-3),         # min 0: the estimator may stop at its first check
+    ("advanced", 5, 3, 9, 4, 1e-3),         # min > max: max decides (worker.cpp:193)
+    ("cornell", 2, 2, 4096, 4096, 1e-3),    # long sequential chains: 4096 samples through every statistics batch
+    ("cornell", 7, 6, 64, 2048, 1e-3),      # adaptive, early acceptance
+    ("advanced", 16, 9, 8, 8, 1e-2),        # large epsilon: shadow thresholds below zero, self-intersection offsets
+    ("box", 11, 13, 8, 8, 1e-6),            # tiny epsilon
+    ("ties", 12, 12, 6, 6, 1e-3),           # 1031 emissive objects: 5 object samples per vertex, duplicated triangles
+])
+def test_unusual_options_vs_oracle(sset, oracle_lib, name, w, h, mn, mx, eps):
+    desc, cam = (_tie_heavy_scene(), scenes.camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, -1.0)) if name == "ties" else sset[name]
+    opt = scenes.options(w, h, mn, mx, eps)
+    scene = binding.Scene(desc)
+    try:
+        img = scene.process_job(cam, opt, base_seed=4321)
+        ys, xs = np.mgrid[0:h, 0:w]
+        xs, ys = xs.ravel().astype(np.int32), ys.ravel().astype(np.int32)
+        states = np.array([binding.seed_to_state(binding.pixel_seed(4321, int(x), int(y))) for x, y in zip(xs, ys)], np.uint64)
+        want, states_after = oracle_lib.scene_create(desc).render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=8)
+        assert_bits_equal(img, want, "%s %dx%d spp %d..%d eps %g" % (name, w, h, mn, mx, eps))
+        # the same pixels as explicit streams: the engines must come back in the oracle's state
+        img2, after = scene.process_item(cam, opt, binding.pixel_streams(xs, ys, states))
+        assert_bits_equal(img2, want, "streams")
+        assert_bits_equal(after, states_after, "engine states after the pixels")
+    finally:
+        scene.close()

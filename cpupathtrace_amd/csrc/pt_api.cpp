@@ -176,6 +176,7 @@ struct pt_scene {
     DevBuf<float> batch_rays;
     DevBuf<uint32_t> walk_hist;
     DevBuf<unsigned long long> shade_wave_counters, trace_wave_counters;
+    hipEvent_t check_event[2 * PT_MAX_GROUPS] = {};
     // suspended walks: two pools per group
     DevBuf<F4> carry_o, carry_d;
     DevBuf<uint4> carry_state;
@@ -185,12 +186,17 @@ struct pt_scene {
     uint32_t shard_capacity = 0;   // per group
     uint32_t ws_groups = 1;        // groups the queue / spill / counter buffers are sized for
     PtTraceConfig trace_cfg{};
-    PtDevCounters *host_counters = nullptr; // pinned, PT_MAX_GROUPS entries
+    PtDevCounters *host_counters = nullptr; // pinned, 2 x PT_MAX_GROUPS entries (the done-check reads the previous batch's copy)
     hipStream_t group_stream[PT_MAX_GROUPS] = {};
 
     ~pt_scene() {
         if(host_counters != nullptr) {
             (void)hipHostFree(host_counters);
+        }
+        for(hipEvent_t e : check_event) {
+            if(e != nullptr) {
+                (void)hipEventDestroy(e);
+            }
         }
         for(hipStream_t gs : group_stream) {
             if(gs != nullptr) {
@@ -325,7 +331,10 @@ int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot, uint32_t g
         s->trace_cfg.walk_hist = s->walk_hist.ptr;
     }
     if(s->host_counters == nullptr) {
-        PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->host_counters), sizeof(PtDevCounters) * PT_MAX_GROUPS, hipHostMallocDefault));
+        PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->host_counters), sizeof(PtDevCounters) * 2 * PT_MAX_GROUPS, hipHostMallocDefault));
+        for(auto &e : s->check_event) {
+            PT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
     }
     for(uint32_t g = 0; g < groups; g++) {
         if(s->group_stream[g] == nullptr) {
@@ -491,11 +500,11 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     }
 
     const bool timing = stats != nullptr;
-    const int kEventPairs = 64;
+    const int kEventPairs = 64; // launches per half of the event ring: a full half is read while the other one fills
     std::vector<hipEvent_t> ev;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     if(timing) {
-        ev.resize(4 * kEventPairs);
+        ev.resize(4 * 2 * kEventPairs);
         for(auto &e : ev) {
             PT_HIP(hipEventCreate(&e));
         }
@@ -505,8 +514,8 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     }
     double trace_ms = 0.0, shade_ms = 0.0;
     uint64_t launches = 0;
-    auto drain_events = [&](int used) -> int {
-        for(int i = 0; i < used; i++) {
+    auto drain_events = [&](int first, int used) -> int {
+        for(int i = first; i < first + used; i++) {
             float a = 0.0F, b = 0.0F;
             PT_HIP(hipEventSynchronize(ev[4 * i + 3]));
             PT_HIP(hipEventElapsedTime(&a, ev[4 * i + 0], ev[4 * i + 1]));
@@ -519,7 +528,9 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
 
     const int check_every = n <= 65536 ? 4 : env_int("PT_CHECK_EVERY", 8);
     uint64_t iterations = 0;
-    int pending = 0;
+    int pending = 0;          // next free pair of the event ring
+    bool other_half_used = false; // the half of the ring that `pending` is not in holds unread events
+    uint64_t batch = 0;
     for(;;) {
         for(int k = 0; k < check_every; k++) {
             for(size_t g = 0; g < G.size(); g++) {
@@ -543,27 +554,41 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
                 launches++;
                 if(timing) {
                     PT_HIP(hipEventRecord(ev[4 * pending + 3], gr.st));
-                    if(++pending == kEventPairs) {
-                        int rc = drain_events(pending);
-                        if(rc != PT_OK) {
-                            return rc;
+                    pending++;
+                    if(pending == kEventPairs || pending == 2 * kEventPairs) {
+                        // this half is full: read the OTHER half (recorded at least 64 launches ago) and continue into it
+                        const int other = pending == kEventPairs ? kEventPairs : 0;
+                        if(other_half_used) {
+                            int rc = drain_events(other, kEventPairs);
+                            if(rc != PT_OK) {
+                                return rc;
+                            }
                         }
-                        pending = 0;
+                        other_half_used = true;
+                        pending = other;
                     }
                 }
             }
             iterations++;
         }
+        // The counters of this batch are copied out behind it; the host looks at the copy of the PREVIOUS batch, so the next batch
+        // is queued while the device still works on this one (a finished frame costs one batch of empty launches).
         bool all_done = true;
+        const size_t slot = static_cast<size_t>(batch & 1U) * PT_MAX_GROUPS, prev_slot = static_cast<size_t>((batch + 1U) & 1U) * PT_MAX_GROUPS;
         for(size_t g = 0; g < G.size(); g++) {
             if(!G[g].done) {
-                PT_HIP(hipMemcpyAsync(s->host_counters + g, s->counters.ptr + g, sizeof(PtDevCounters), hipMemcpyDeviceToHost, G[g].st));
+                PT_HIP(hipMemcpyAsync(s->host_counters + slot + g, s->counters.ptr + g, sizeof(PtDevCounters), hipMemcpyDeviceToHost, G[g].st));
+                PT_HIP(hipEventRecord(s->check_event[(batch & 1U) * PT_MAX_GROUPS + g], G[g].st));
             }
         }
         for(size_t g = 0; g < G.size(); g++) {
             if(!G[g].done) {
-                PT_HIP(hipStreamSynchronize(G[g].st));
-                const unsigned long long finished = s->host_counters[g].streams_done;
+                if(batch == 0) {
+                    all_done = false;
+                    continue;
+                }
+                PT_HIP(hipEventSynchronize(s->check_event[((batch + 1U) & 1U) * PT_MAX_GROUPS + g]));
+                const unsigned long long finished = s->host_counters[prev_slot + g].streams_done;
                 G[g].done = finished >= G[g].count;
                 // Endgame: once most streams have rendered all their pixels the launches are small, and suspending the long walks
                 // of the remaining streams only multiplies the number of (fixed-cost) iterations they need.
@@ -574,6 +599,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
             }
             all_done = all_done && G[g].done;
         }
+        batch++;
         PT_HIP(hipGetLastError());
         if(all_done) {
             break;
@@ -589,7 +615,14 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     }
     (void)hipEventDestroy(ev_init);
     if(timing) {
-        int rc = drain_events(pending);
+        int rc = PT_OK;
+        if(other_half_used) {
+            rc = drain_events(pending < kEventPairs ? kEventPairs : 0, kEventPairs);
+        }
+        if(rc == PT_OK) {
+            const int first = pending < kEventPairs ? 0 : kEventPairs;
+            rc = drain_events(first, pending - first);
+        }
         if(rc != PT_OK) {
             return rc;
         }

@@ -251,8 +251,10 @@ PtQueue make_queue(pt_scene *s, uint32_t group = 0) {
     const size_t rays = static_cast<size_t>(s->shard_capacity) * PT_SHARDS;
     q.ray_o = reinterpret_cast<float4 *>(s->q_ray_o.ptr) + group * rays;
     q.ray_d = reinterpret_cast<float4 *>(s->q_ray_d.ptr) + group * rays;
-    q.count = s->q_header.ptr + static_cast<size_t>(group) * 2 * PT_SHARDS * PT_QSTRIDE;
+    // two headers per group (count[8] + head[8] words each), used by alternate launches
+    q.count = s->q_header.ptr + static_cast<size_t>(group) * 4 * PT_SHARDS * PT_QSTRIDE;
     q.head = q.count + PT_SHARDS * PT_QSTRIDE;
+    q.next_header = nullptr;
     q.shard_capacity = s->shard_capacity;
     return q;
 }
@@ -305,7 +307,7 @@ int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot, uint32_t g
         s->shard_capacity = cap;
         s->ws_groups = groups;
     }
-    PT_HIP(s->q_header.ensure(static_cast<size_t>(PT_MAX_GROUPS) * 2 * PT_SHARDS * PT_QSTRIDE));
+    PT_HIP(s->q_header.ensure(static_cast<size_t>(PT_MAX_GROUPS) * 4 * PT_SHARDS * PT_QSTRIDE));
     PT_HIP(s->counters.ensure(PT_MAX_GROUPS));
     PT_HIP(s->shade_wave_counters.ensure(2 * (static_cast<size_t>(n) / 64 + PT_MAX_GROUPS)));
     PT_HIP(s->trace_wave_counters.ensure(static_cast<size_t>(s->trace_cfg.grid) * 4 * 8 * groups));
@@ -492,6 +494,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     PT_HIP(hipEventCreateWithFlags(&ev_init, hipEventDisableTiming));
     PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters) * PT_MAX_GROUPS, s->stream));
     PT_HIP(hipMemsetAsync(s->carry_header.ptr, 0, static_cast<size_t>(PT_MAX_GROUPS) * 4 * PT_QSTRIDE * sizeof(uint32_t), s->stream));
+    PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, s->q_header.count * sizeof(uint32_t), s->stream));
     PT_HIP(hipMemsetAsync(s->shade_wave_counters.ptr, 0, s->shade_wave_counters.count * sizeof(unsigned long long), s->stream));
     PT_HIP(hipMemsetAsync(s->trace_wave_counters.ptr, 0, s->trace_wave_counters.count * sizeof(unsigned long long), s->stream));
     PT_HIP(hipEventRecord(ev_init, s->stream));
@@ -539,18 +542,22 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
                     continue;
                 }
                 PtDevCounters *cnt = s->counters.ptr + g;
-                PT_HIP(hipMemsetAsync(gr.q.count, 0, 2 * PT_SHARDS * PT_QSTRIDE * sizeof(uint32_t), gr.st));
                 if(timing) {
                     PT_HIP(hipEventRecord(ev[4 * pending + 0], gr.st));
                 }
                 const int parity = static_cast<int>(iterations & 1U);
                 gr.cfg.parity = parity;
-                pt_launch_shade(gr.st, s->dev, cam, opt, gr.P, gr.q, gr.carry, parity, shard_mode, d_image, cnt);
+                // this launch's queue header, and the other one for the shading kernel to clear (both were zeroed before the loop)
+                PtQueue q_now = gr.q;
+                q_now.count = gr.q.count + static_cast<size_t>(parity) * 2 * PT_SHARDS * PT_QSTRIDE;
+                q_now.head = q_now.count + PT_SHARDS * PT_QSTRIDE;
+                q_now.next_header = gr.q.count + static_cast<size_t>(parity ^ 1) * 2 * PT_SHARDS * PT_QSTRIDE;
+                pt_launch_shade(gr.st, s->dev, cam, opt, gr.P, q_now, gr.carry, parity, shard_mode, d_image, cnt);
                 if(timing) {
                     PT_HIP(hipEventRecord(ev[4 * pending + 1], gr.st));
                     PT_HIP(hipEventRecord(ev[4 * pending + 2], gr.st));
                 }
-                pt_launch_trace(gr.st, s->dev, gr.q, gr.carry, gr.P, gr.cfg, cnt);
+                pt_launch_trace(gr.st, s->dev, q_now, gr.carry, gr.P, gr.cfg, cnt);
                 launches++;
                 if(timing) {
                     PT_HIP(hipEventRecord(ev[4 * pending + 3], gr.st));

@@ -50,6 +50,7 @@ struct PtQueue {
     uint32_t *count; // [PT_SHARDS * PT_QSTRIDE] rays appended to shard s at count[s * PT_QSTRIDE]
     uint32_t *head;  // [PT_SHARDS * PT_QSTRIDE] rays dequeued from shard s at head[s * PT_QSTRIDE]
     uint32_t shard_capacity;
+    uint32_t *next_header; // count and head words of the NEXT launch (the headers alternate): cleared by the shading kernel, or null
 };
 
 // Walks suspended by one traversal launch and resumed by the next one (two pools used alternately).  A launch gives every walk

@@ -319,6 +319,10 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void pt_shade_kernel(PtDevScen
         carry.count[(parity ^ 1) * PT_QSTRIDE] = 0;
         carry.head[parity * PT_QSTRIDE] = 0;
     }
+    if(q.next_header != nullptr && p < 2 * PT_SHARDS) {
+        // the queue headers alternate between launches: the one the next launch appends to was last read two kernels ago
+        q.next_header[p * PT_QSTRIDE] = 0;
+    }
 
     uint32_t flags = PT_F_DONE;
     if(p < P.n) {

@@ -29,12 +29,28 @@ def up_to_date():
 
 
 def build(force=False, verbose=False):
+    """Compile the library unless it is up to date.  Safe when several processes (the ranks of a multi-GPU run) call it at once:
+    one of them compiles, into a temporary file that is renamed into place, the others wait for the lock and find the result."""
     if not force and up_to_date():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and up_to_date():
+                return LIB
+            tmp = "%s.%d.tmp" % (LIB, os.getpid())
+            cmd = [hipcc()] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

@@ -682,10 +682,11 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
 }
 
 uint32_t choose_groups(const pt_scene *s, uint32_t n) {
-    // Measured: when the whole scene lives in LDS the shading kernel takes almost half of the time and two groups
-    // of streams on two HIP streams overlap one group's shading with the other's traversal (+10 %); with an HBM-resident tree the
-    // traversal dominates and splitting the streams only shortens its launches (-4 %).
-    const int by_scene = s->trace_cfg.lds_mode == 2 ? 2 : 1;
+    // Measured: when the whole scene lives in LDS the shading kernel takes half of the time and three groups of
+    // streams on three HIP streams overlap one group's shading with the others' traversal (+23 % on the Cornell scene, +13 % with
+    // two, -3 % with four); with an HBM-resident tree the traversal dominates and splitting the streams only shortens its launches
+    // (-4 %).
+    const int by_scene = s->trace_cfg.lds_mode == 2 ? 3 : 1;
     const int want = std::min(std::max(env_int("PT_GROUPS", by_scene), 1), PT_MAX_GROUPS);
     // a group should still fill the chip's lanes on its own now and then: at least 128 K streams per group
     const uint32_t by_size = std::max<uint32_t>(1U, n / 131072U);

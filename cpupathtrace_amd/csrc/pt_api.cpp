@@ -188,6 +188,7 @@ struct pt_scene {
     PtTraceConfig trace_cfg{};
     PtDevCounters *host_counters = nullptr; // pinned, 2 x PT_MAX_GROUPS entries (the done-check reads the previous batch's copy)
     hipStream_t group_stream[PT_MAX_GROUPS] = {};
+    uint32_t concurrent_streams = 0; // group streams found to run side by side (pick_concurrent_streams)
 
     ~pt_scene() {
         if(host_counters != nullptr) {
@@ -198,9 +199,10 @@ struct pt_scene {
                 (void)hipEventDestroy(e);
             }
         }
-        for(hipStream_t gs : group_stream) {
-            if(gs != nullptr) {
-                (void)hipStreamDestroy(gs);
+        for(size_t g = 0; g < PT_MAX_GROUPS; g++) {
+            // (later entries may repeat an earlier stream when the runtime offered fewer concurrent ones than groups)
+            if(group_stream[g] != nullptr && std::find(group_stream, group_stream + g, group_stream[g]) == group_stream + g) {
+                (void)hipStreamDestroy(group_stream[g]);
             }
         }
         if(stream != nullptr) {
@@ -274,6 +276,68 @@ PtCarry make_carry(pt_scene *s, uint32_t group = 0) {
     return c;
 }
 
+// Group streams that really run side by side.  The runtime multiplexes HIP streams onto a few hardware queues (four by default),
+// and kernels of two streams that share a queue run one after the other -- which stream lands on which queue depends on what else
+// the process has created.  Candidates are therefore PROBED: a 400 us do-nothing kernel on each of two streams takes 400 us when
+// they are concurrent and 800 us when they are not.  `wanted` streams that are pairwise concurrent are kept; if the runtime offers
+// fewer, the later groups share the last stream found (they then simply queue up).
+int pick_concurrent_streams(pt_scene *s, uint32_t wanted) {
+    using clock = std::chrono::steady_clock;
+    std::vector<hipStream_t> candidates, chosen;
+    for(hipStream_t gs : s->group_stream) {
+        if(gs != nullptr && std::find(chosen.begin(), chosen.end(), gs) == chosen.end()) {
+            chosen.push_back(gs); // streams picked earlier stay
+        }
+    }
+    auto concurrent = [&](hipStream_t a, hipStream_t b, bool &result) -> int {
+        PT_HIP(hipStreamSynchronize(a));
+        PT_HIP(hipStreamSynchronize(b));
+        const auto t0 = clock::now();
+        pt_launch_spin(a, 400);
+        pt_launch_spin(b, 400);
+        PT_HIP(hipStreamSynchronize(a));
+        PT_HIP(hipStreamSynchronize(b));
+        const double us = std::chrono::duration<double, std::micro>(clock::now() - t0).count();
+        result = us < 650.0;
+        return PT_OK;
+    };
+    const int max_candidates = 12;
+    for(int i = 0; i < max_candidates && chosen.size() < wanted; i++) {
+        hipStream_t c = nullptr;
+        PT_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        candidates.push_back(c);
+        pt_launch_spin(c, 1); // first use of a stream may create its queue: keep that out of the probe
+        bool ok = true;
+        for(hipStream_t other : chosen) {
+            bool side_by_side = false;
+            int rc = concurrent(c, other, side_by_side);
+            if(rc != PT_OK) {
+                return rc;
+            }
+            if(!side_by_side) {
+                ok = false;
+                break;
+            }
+        }
+        if(ok) {
+            chosen.push_back(c);
+        }
+    }
+    for(hipStream_t c : candidates) {
+        if(std::find(chosen.begin(), chosen.end(), c) == chosen.end()) {
+            (void)hipStreamDestroy(c);
+        }
+    }
+    s->concurrent_streams = static_cast<uint32_t>(chosen.size());
+    for(uint32_t g = 0; g < PT_MAX_GROUPS; g++) {
+        s->group_stream[g] = chosen.empty() ? nullptr : (g < chosen.size() ? chosen[g] : (g < wanted ? chosen.back() : nullptr));
+    }
+    if(env_int("PT_DEBUG", 0) != 0) {
+        std::fprintf(stderr, "[pt] %zu of %u wanted group streams run concurrently (probed %zu candidates)\n", chosen.size(), wanted, candidates.size());
+    }
+    return chosen.empty() ? fail(PT_ERR_HIP, "no usable HIP stream") : PT_OK;
+}
+
 // workspace for n stream slots and a queue of `queue_rays_per_slot` rays per slot
 int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot, uint32_t groups = 1) {
     // each group holds ceil(n / groups) slots (rounded up to whole 2048-slot units, see group_ranges)
@@ -338,10 +402,14 @@ int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot, uint32_t g
             PT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
     }
-    for(uint32_t g = 0; g < groups; g++) {
-        if(s->group_stream[g] == nullptr) {
-            PT_HIP(hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking));
+    if(groups > 1 && s->group_stream[groups - 1] == nullptr) {
+        int rc = pick_concurrent_streams(s, groups);
+        if(rc != PT_OK) {
+            return rc;
         }
+    }
+    else if(s->group_stream[0] == nullptr) {
+        PT_HIP(hipStreamCreateWithFlags(&s->group_stream[0], hipStreamNonBlocking));
     }
     return PT_OK;
 }
@@ -481,6 +549,11 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         // no more workgroups than the rays one iteration can produce
         const uint64_t blocks = (static_cast<uint64_t>(gr.count) * rays_per_slot + 255) / 256;
         gr.cfg.grid = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(gr.cfg.grid), blocks)));
+        if(groups > 1 && gr.cfg.lds_mode != 2) {
+            // concurrent groups share the CUs: two persistent workgroups per CU each (three groups fill a CU's LDS and wave slots)
+            const int per_cu = std::max(env_int("PT_GROUP_BLOCKS_PER_CU", 2), 1);
+            gr.cfg.grid = std::min(gr.cfg.grid, s->cu_count * per_cu);
+        }
         gr.cfg.spill = s->spill.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 256 * s->trace_cfg.spill_depth;
         gr.cfg.wave_counters = s->trace_wave_counters.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 32;
         gr.st = s->group_stream[n_groups];
@@ -682,11 +755,11 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
 }
 
 uint32_t choose_groups(const pt_scene *s, uint32_t n) {
-    // Measured: when the whole scene lives in LDS the shading kernel takes half of the time and three groups of
-    // streams on three HIP streams overlap one group's shading with the others' traversal (+23 % on the Cornell scene, +13 % with
-    // two, -3 % with four); with an HBM-resident tree the traversal dominates and splitting the streams only shortens its launches
-    // (-4 %).
-    const int by_scene = s->trace_cfg.lds_mode == 2 ? 3 : 1;
+    // Measured: three groups of streams on three HIP streams, so that one group's shading (and the thin end of its
+    // traversal launches) overlaps the others' traversal.  Scenes that live in LDS: +23 % (two groups +13 %, four -3 %).  HBM-resident
+    // trees: +12 %, provided every group's persistent traversal grid is limited to two workgroups per CU (run_wavefront) -- with
+    // full-size grids the kernels of the groups only queue up behind each other (-4 %).
+    const int by_scene = 3;
     const int want = std::min(std::max(env_int("PT_GROUPS", by_scene), 1), PT_MAX_GROUPS);
     // a group should still fill the chip's lanes on its own now and then: at least 128 K streams per group
     const uint32_t by_size = std::max<uint32_t>(1U, n / 131072U);

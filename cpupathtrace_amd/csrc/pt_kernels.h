@@ -91,6 +91,8 @@ struct PtTraceConfig {
 
 void pt_launch_init_tiles(hipStream_t stream, PtPaths paths, const int4 *tiles, const uint32_t *tile_offset, uint32_t n_tiles, uint64_t base_seed);
 void pt_launch_init_streams(hipStream_t stream, PtPaths paths);
+// one wavefront that does nothing for `microseconds` (probe: do two HIP streams run their kernels at the same time?)
+void pt_launch_spin(hipStream_t stream, uint32_t microseconds);
 void pt_launch_shade(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtPaths paths, PtQueue queue,
                      PtCarry carry, int parity, int shard_mode, float4 *image, PtDevCounters *counters);
 void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue, PtCarry carry, PtPaths paths, const PtTraceConfig &cfg,

@@ -722,7 +722,18 @@ __global__ void pt_init_streams_kernel(PtPaths P) {
     P.nee_mask[p] = 0;
 }
 
+__global__ void pt_spin_kernel(unsigned long long ticks) {
+    const unsigned long long start = wall_clock64(); // constant 100 MHz
+    while(wall_clock64() - start < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 } // namespace
+
+void pt_launch_spin(hipStream_t stream, uint32_t microseconds) {
+    hipLaunchKernelGGL(pt_spin_kernel, dim3(1), dim3(64), 0, stream, 100ULL * microseconds);
+}
 
 uint64_t pt_host_pixel_seed(uint64_t base, int32_t x, int32_t y) {
     uint64_t z = base + 0x9E3779B97F4A7C15ULL * (1ULL + (((uint64_t)(uint32_t)y) << 32) + (uint64_t)(uint32_t)x);

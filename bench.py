@@ -90,10 +90,12 @@ def ref_formula_bytes_per_sample(R, A, T, V):
     return R * (A * 32.0 + T * 36.0 + 96.0) + V * 100.0 + 16.0
 
 
-def measured_traffic(workload_key, launches_scale=1.0):
+def measured_traffic(workload_key, samples_per_launch):
     """HBM bytes per launch of the dominant kernel from the newest profiles/r*_traffic.json (written by tools/measure_traffic.py
     from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same workload, with the gfx950 correction of
-    MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request, calibrated on tools/gather_bench.hip).  None if absent."""
+    MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request, calibrated on tools/gather_bench.hip).  The profile stores
+    bytes per SAMPLE (the profiler serialises kernels, so its frame runs as one stream group with three times larger launches);
+    a launch of this run carries `samples_per_launch` samples.  None if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     for path in reversed(files):
@@ -101,10 +103,11 @@ def measured_traffic(workload_key, launches_scale=1.0):
             entry = json.load(open(path)).get(workload_key)
         except (OSError, ValueError):
             continue
+        if entry and entry.get("bytes_per_sample"):
+            return entry["bytes_per_sample"] * samples_per_launch, os.path.relpath(path, ROOT)
         if entry:
             return entry.get("bytes_per_launch"), os.path.relpath(path, ROOT)
     return None, None
-
 
 def cpu_baseline(sc, cam, opt, seconds_target):
     """The reference itself (oracle/_ref, kind "reference") or, if that was not built, the C restatement (kind "port"),
@@ -226,12 +229,19 @@ def main():
         V = s["vertices"] / samples
         bytes_per_sample = ref_formula_bytes_per_sample(R, A, T, V)
         launches = max(s["iterations"], 1)
-        trace_s = s["trace_ms"] / 1e3
-        achieved = bytes_per_sample * samples / max(trace_s, 1e-9) / 1e9
-        traffic, traffic_source = measured_traffic("%s-%d" % (args.workload, args.mesh_n if args.workload.startswith("dragon") else 0))
+        # The streams are rendered as `groups` concurrent groups: `concurrent` launches of the kernel run side by side on average, each
+        # on a share of the CUs.  One launch: algorithmic bytes per launch / its duration (HIP events on its stream; this is what
+        # rocprofv3's average duration shows).  The chip: that times the launches running at once = all bytes / the time during which
+        # at least one launch was running.
+        busy_s = max(s.get("trace_busy_ms", s["trace_ms"]), 1e-6) / 1e3
+        concurrent = (s["trace_ms"] / 1e3) / busy_s
+        achieved = bytes_per_sample * samples / busy_s / 1e9
+        traffic, traffic_source = measured_traffic("%s-%d" % (args.workload, args.mesh_n if args.workload.startswith("dragon") else 0), samples / launches)
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_per_sample * samples / launches,
                     "kernel": "pt_trace_kernel", "avg_launch_ms": s["trace_ms"] / launches, "launches_per_step": launches,
+                    "concurrent_launches": concurrent, "stream_groups": s.get("groups", 1), "trace_busy_ms": busy_s * 1e3,
+                    "achieved_per_launch": bytes_per_sample * samples / launches / max(s["trace_ms"] / launches / 1e3, 1e-9) / 1e9,
                     "algorithmic_bytes_per_sample": bytes_per_sample,
                     "per_sample": {"rays": R, "aabb_tests_per_ray": A, "leaf_tests_per_ray": T, "vertices": V},
                     "trace_ms": s["trace_ms"], "shade_ms": s["shade_ms"], "step_device_ms": s["total_ms"]}

@@ -64,7 +64,7 @@ class Options(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_traced", C.c_uint64), ("shadow_rays_traced", C.c_uint64), ("node_visits", C.c_uint64),
                 ("leaf_tests", C.c_uint64), ("vertices", C.c_uint64), ("iterations", C.c_uint64), ("trace_ms", C.c_double),
-                ("shade_ms", C.c_double), ("total_ms", C.c_double)]
+                ("shade_ms", C.c_double), ("total_ms", C.c_double), ("trace_busy_ms", C.c_double), ("groups", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

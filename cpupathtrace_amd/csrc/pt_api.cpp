@@ -590,14 +590,17 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     }
     double trace_ms = 0.0, shade_ms = 0.0;
     uint64_t launches = 0;
+    std::vector<std::pair<float, float>> trace_intervals; // [start, end) of every traversal launch, ms since ev_begin
     auto drain_events = [&](int first, int used) -> int {
         for(int i = first; i < first + used; i++) {
-            float a = 0.0F, b = 0.0F;
+            float a = 0.0F, b = 0.0F, t0 = 0.0F;
             PT_HIP(hipEventSynchronize(ev[4 * i + 3]));
             PT_HIP(hipEventElapsedTime(&a, ev[4 * i + 0], ev[4 * i + 1]));
             PT_HIP(hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3]));
+            PT_HIP(hipEventElapsedTime(&t0, ev_begin, ev[4 * i + 2]));
             shade_ms += a;
             trace_ms += b;
+            trace_intervals.emplace_back(t0, t0 + b);
         }
         return PT_OK;
     };
@@ -743,6 +746,25 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         stats->vertices = c.vertices;
         stats->iterations = launches;
         stats->trace_ms = trace_ms;
+        {
+            // union of the traversal launches' intervals (the groups' launches overlap)
+            std::sort(trace_intervals.begin(), trace_intervals.end());
+            double busy = 0.0;
+            float open_from = 0.0F, open_to = -1.0F;
+            for(const auto &iv : trace_intervals) {
+                if(iv.first > open_to) {
+                    busy += open_to > open_from ? static_cast<double>(open_to - open_from) : 0.0;
+                    open_from = iv.first;
+                    open_to = iv.second;
+                }
+                else {
+                    open_to = std::max(open_to, iv.second);
+                }
+            }
+            busy += open_to > open_from ? static_cast<double>(open_to - open_from) : 0.0;
+            stats->trace_busy_ms = busy;
+            stats->groups = G.size();
+        }
         stats->shade_ms = shade_ms;
         stats->total_ms = total;
         for(auto &e : ev) {
@@ -754,7 +776,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     return PT_OK;
 }
 
-uint32_t choose_groups(const pt_scene *s, uint32_t n) {
+uint32_t choose_groups(pt_scene *s, uint32_t n) {
     // Measured: three groups of streams on three HIP streams, so that one group's shading (and the thin end of its
     // traversal launches) overlaps the others' traversal.  Scenes that live in LDS: +23 % (two groups +13 %, four -3 %).  HBM-resident
     // trees: +12 %, provided every group's persistent traversal grid is limited to two workgroups per CU (run_wavefront) -- with
@@ -763,7 +785,15 @@ uint32_t choose_groups(const pt_scene *s, uint32_t n) {
     const int want = std::min(std::max(env_int("PT_GROUPS", by_scene), 1), PT_MAX_GROUPS);
     // a group should still fill the chip's lanes on its own now and then: at least 128 K streams per group
     const uint32_t by_size = std::max<uint32_t>(1U, n / 131072U);
-    return std::min<uint32_t>(static_cast<uint32_t>(want), by_size);
+    uint32_t groups = std::min<uint32_t>(static_cast<uint32_t>(want), by_size);
+    if(groups > 1) {
+        // no more groups than streams that really run side by side (groups sharing a stream would only queue up)
+        if(s->group_stream[groups - 1] == nullptr && pick_concurrent_streams(s, groups) != PT_OK) {
+            return 1;
+        }
+        groups = std::max<uint32_t>(1U, std::min<uint32_t>(groups, s->concurrent_streams));
+    }
+    return groups;
 }
 
 } // namespace

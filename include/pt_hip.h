@@ -112,6 +112,8 @@ typedef struct pt_stats {
     double trace_ms;            /* summed duration of the traversal kernel launches */
     double shade_ms;            /* summed duration of the shading kernel launches */
     double total_ms;            /* first launch to last completion */
+    double trace_busy_ms;       /* time during which at least one traversal launch was running (groups of streams run concurrently) */
+    uint64_t groups;            /* stream groups the job was split into */
 } pt_stats;
 
 typedef struct pt_scene pt_scene;

@@ -10,6 +10,7 @@ line misses L2 87 % of the time)."""
 import csv, glob, json, sys
 
 key, fetch_dir, write_dir, out = sys.argv[1:5]
+samples = float(sys.argv[5]) if len(sys.argv) > 5 else 64.0 * 1024 * 1024  # samples of the profiled frame (bench.py --spp 64)
 
 
 def per_launch(root, counter):
@@ -26,7 +27,8 @@ fetch_kib, n1 = per_launch(fetch_dir, "FETCH_SIZE")
 write_kib, n2 = per_launch(write_dir, "WRITE_SIZE")
 entry = {"kernel": "pt_trace_kernel", "fetch_size_kib_per_launch": fetch_kib, "write_size_kib_per_launch": write_kib, "launches": n1,
          "bytes_per_launch": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0,
-         "note": "2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes over `python bench.py --spp 64 --cpu-seconds 0 --warmup 0`"}
+         "bytes_per_sample": (2.0 * fetch_kib * 1024.0 + write_kib * 1024.0) * n1 / samples,
+         "note": "2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes over `python bench.py --spp 64 --cpu-seconds 0 --warmup 0`; the profiler runs kernels one at a time, so the frame is rendered as ONE stream group there (launches = that frame's); bytes_per_sample carries over to any grouping"}
 try:
     data = json.load(open(out))
 except (OSError, ValueError):

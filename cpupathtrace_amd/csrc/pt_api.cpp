@@ -529,6 +529,7 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     const int endgame_percent = std::min(std::max(env_int("PT_ENDGAME_PERCENT", 90), 1), 101);
     const int max_steps_env = env_int("PT_MAX_STEPS", 256);
     const int max_steps = max_steps_env > 0 ? max_steps_env : 0x7fffffff;
+    const int group_blocks_per_cu = std::max(env_int("PT_GROUP_BLOCKS_PER_CU", 2), 1);
     const uint32_t per_group = ((n + groups - 1) / groups + 2047U) / 2048U * 2048U;
     uint32_t n_groups = 0;
     for(uint32_t g = 0; g < groups; g++) {
@@ -550,9 +551,10 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
         const uint64_t blocks = (static_cast<uint64_t>(gr.count) * rays_per_slot + 255) / 256;
         gr.cfg.grid = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(gr.cfg.grid), blocks)));
         if(groups > 1 && gr.cfg.lds_mode != 2) {
-            // concurrent groups share the CUs: two persistent workgroups per CU each (three groups fill a CU's LDS and wave slots)
-            const int per_cu = std::max(env_int("PT_GROUP_BLOCKS_PER_CU", 2), 1);
-            gr.cfg.grid = std::min(gr.cfg.grid, s->cu_count * per_cu);
+            // concurrent groups share the CUs: two persistent workgroups per CU each (three groups fill a CU's LDS and wave slots).
+            // (Giving the groups that are still rendering the CUs of the finished ones was measured: no gain -- by then they are in
+            // the latency-bound end of the frame.)
+            gr.cfg.grid = std::min(gr.cfg.grid, s->cu_count * group_blocks_per_cu);
         }
         gr.cfg.spill = s->spill.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 256 * s->trace_cfg.spill_depth;
         gr.cfg.wave_counters = s->trace_wave_counters.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 32;
@@ -1512,16 +1514,12 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
         return rc;
     }
     const PtDevCamera cam = derive_camera(camera);
-    std::vector<int4> rects(n_tiles);
-    std::vector<uint32_t> offsets(n_tiles);
     uint64_t total = 0;
     for(size_t i = 0; i < n_tiles; i++) {
         const pt_tile &t = tiles[i];
         if(t.w <= 0 || t.h <= 0 || t.x < 0 || t.y < 0 || t.x + t.w > options->image_width || t.y + t.h > options->image_height) {
             return fail(PT_ERR_INVALID, "tile outside the image or empty");
         }
-        rects[i] = make_int4(t.x, t.y, t.w, t.h);
-        offsets[i] = static_cast<uint32_t>(total);
         total += static_cast<uint64_t>(t.w) * static_cast<uint64_t>(t.h);
     }
     if(total > 0x0fffffffULL) {
@@ -1529,6 +1527,25 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
     }
     const uint32_t n32 = static_cast<uint32_t>(total);
     const uint32_t groups = choose_groups(s, n32);
+    // Stream slots are laid out tile after tile and the stream groups are contiguous ranges of slots: with the tiles in the caller's
+    // (row-major) order a group is a horizontal band of the frame.  That is deliberate: the bands differ in cost, so the groups reach
+    // the thin end of their work at different times and one group's tail overlaps the others' full launches (dealing the tiles out
+    // to the groups in turn was measured: -2 %).
+    std::vector<size_t> order(n_tiles);
+    for(size_t i = 0; i < n_tiles; i++) {
+        order[i] = i;
+    }
+    std::vector<int4> rects(n_tiles);
+    std::vector<uint32_t> offsets(n_tiles);
+    {
+        uint64_t at = 0;
+        for(size_t k = 0; k < n_tiles; k++) {
+            const pt_tile &t = tiles[order[k]];
+            rects[k] = make_int4(t.x, t.y, t.w, t.h);
+            offsets[k] = static_cast<uint32_t>(at);
+            at += static_cast<uint64_t>(t.w) * static_cast<uint64_t>(t.h);
+        }
+    }
     rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples, groups);
     if(rc != PT_OK) {
         return rc;

@@ -1531,16 +1531,12 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
     // (row-major) order a group is a horizontal band of the frame.  That is deliberate: the bands differ in cost, so the groups reach
     // the thin end of their work at different times and one group's tail overlaps the others' full launches (dealing the tiles out
     // to the groups in turn was measured: -2 %).
-    std::vector<size_t> order(n_tiles);
-    for(size_t i = 0; i < n_tiles; i++) {
-        order[i] = i;
-    }
     std::vector<int4> rects(n_tiles);
     std::vector<uint32_t> offsets(n_tiles);
     {
         uint64_t at = 0;
         for(size_t k = 0; k < n_tiles; k++) {
-            const pt_tile &t = tiles[order[k]];
+            const pt_tile &t = tiles[k];
             rects[k] = make_int4(t.x, t.y, t.w, t.h);
             offsets[k] = static_cast<uint32_t>(at);
             at += static_cast<uint64_t>(t.w) * static_cast<uint64_t>(t.h);

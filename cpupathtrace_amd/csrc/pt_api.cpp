@@ -290,15 +290,18 @@ int pick_concurrent_streams(pt_scene *s, uint32_t wanted) {
         }
     }
     auto concurrent = [&](hipStream_t a, hipStream_t b, bool &result) -> int {
-        PT_HIP(hipStreamSynchronize(a));
-        PT_HIP(hipStreamSynchronize(b));
-        const auto t0 = clock::now();
-        pt_launch_spin(a, 400);
-        pt_launch_spin(b, 400);
-        PT_HIP(hipStreamSynchronize(a));
-        PT_HIP(hipStreamSynchronize(b));
-        const double us = std::chrono::duration<double, std::micro>(clock::now() - t0).count();
-        result = us < 650.0;
+        double best = 1e30;
+        for(int attempt = 0; attempt < 2; attempt++) { // the faster of two tries: a slow first launch must not look like queueing
+            PT_HIP(hipStreamSynchronize(a));
+            PT_HIP(hipStreamSynchronize(b));
+            const auto t0 = clock::now();
+            pt_launch_spin(a, 400);
+            pt_launch_spin(b, 400);
+            PT_HIP(hipStreamSynchronize(a));
+            PT_HIP(hipStreamSynchronize(b));
+            best = std::min(best, std::chrono::duration<double, std::micro>(clock::now() - t0).count());
+        }
+        result = best < 650.0;
         return PT_OK;
     };
     const int max_candidates = 12;

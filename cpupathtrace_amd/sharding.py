@@ -33,8 +33,12 @@ class ShardedJob:
     render_fn(tiles, image_tensor, want_stats) renders the given tiles into the (height, width, 4) float32 tensor on this
     rank's device; the default calls the HIP library.  Tests pass their own to exercise the sharding on CPU/gloo."""
 
-    def __init__(self, scene, camera, options, rank, world, device, base_seed=1234, render_fn=None):
+    def __init__(self, scene, camera, options, rank, world, device, base_seed=1234, render_fn=None, staged_gather=False):
+        """staged_gather: move the chunks through host memory around the gather (gloo has no device gather; used to rehearse the
+        N > 1 path with several ranks on ONE GPU -- RCCL wants one device per rank)."""
         self.scene, self.camera, self.options = scene, camera, options
+        self.staged_gather = staged_gather
+        self.gather_bytes = 0
         self.rank, self.world, self.device, self.base_seed = rank, world, device, base_seed
         self.width, self.height = options["image_width"], options["image_height"]
         self.tiles = binding.job_tiles(self.width, self.height) if scene is not None else _tiles_py(self.width, self.height)
@@ -47,9 +51,11 @@ class ShardedJob:
             self.chunk = max(len(p) for p in per_rank)
             self.my_index = torch.from_numpy(per_rank[rank]).to(device)
             self.send = torch.zeros((self.chunk, 4), dtype=torch.float32, device=device)
+            self.gather_bytes = self.chunk * 16 * (world - 1)  # what rank 0 receives from the other ranks per frame
+            xdev = torch.device("cpu") if staged_gather else device
             if rank == 0:
                 self.all_index = [torch.from_numpy(p).to(device) for p in per_rank]
-                self.recv = [torch.zeros((self.chunk, 4), dtype=torch.float32, device=device) for _ in range(world)]
+                self.recv = [torch.zeros((self.chunk, 4), dtype=torch.float32, device=xdev) for _ in range(world)]
 
     def _render_hip(self, tiles, image, want_stats):
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -62,11 +68,11 @@ class ShardedJob:
         if self.world > 1:
             flat = self.image.view(-1, 4)
             self.send[: len(self.my_index)] = flat[self.my_index]
-            dist.gather(self.send, self.recv if self.rank == 0 else None, dst=0)
+            dist.gather(self.send.cpu() if self.staged_gather else self.send, self.recv if self.rank == 0 else None, dst=0)
             if self.rank == 0:
                 for r in range(1, self.world):
                     idx = self.all_index[r]
-                    flat[idx] = self.recv[r][: len(idx)]
+                    flat[idx] = self.recv[r][: len(idx)].to(flat.device)
         return stats
 
 

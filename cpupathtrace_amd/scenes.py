@@ -235,6 +235,22 @@ def box_scene(aspect_ratio=-1.0):
     return sb.build(), camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, aspect_ratio)
 
 
+def oneway_mirror_scene(aspect_ratio=-1.0):
+    """Box of benchmark/main.cpp:34-57 with the two mirror kinds of src/scene/propagation.cpp:178-217 in it: a MirrorBRDF(one_way = true)
+    pane across the middle of the box (reflects rays that meet its front, lets rays from behind pass: propagation.cpp:186-190,210-212),
+    a tilted two-sided mirror quad behind it and a two-sided mirror sphere in front of it, so that paths meet the pane from both sides."""
+    sb = SceneBuilder()
+    sb.triangles(make_box((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), sb.material((0.9, 0.8, 0.7, 1.0)))
+    light = sb.material((1, 1, 1, 1), 1.0, (1, 1, 1, 1))
+    sb.triangles(make_plane((-0.25, F(1.0) - F(0.01), -0.25), (0.25, F(1.0) - F(0.01), 0.25)), light)
+    pane = sb.material((1, 1, 1, 1), bsdf=BSDF_MIRROR, one_way=True, specular=(0.9, 0.95, 1.0, 1.0))
+    sb.triangles(make_plane((-0.7, -0.8, 0.1), (0.6, 0.5, 0.1)), pane)                      # normal along z: front faces the camera or not by winding
+    sb.triangles([[(-0.9, -0.9, 0.8), (0.9, -0.9, 0.5), (0.0, 0.9, 0.9)]], sb.material((1, 1, 1, 1), bsdf=BSDF_MIRROR, specular=(1.0, 0.9, 0.8, 1.0)))
+    sb.sphere((0.45, -0.55, -0.4), 0.3, sb.material((0, 0, 1, 1), bsdf=BSDF_MIRROR, one_way=True))
+    sb.sphere((-0.5, -0.6, -0.3), 0.25, sb.material((0, 0, 1, 1), bsdf=BSDF_MIRROR))
+    return sb.build(), camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, aspect_ratio)
+
+
 def dragon_box_scene(mesh_pos, mesh_nrm, aspect_ratio=-1.0, copies=1):
     """benchmark/main.cpp:59-105 renderSceneDragonBox with `mesh` in the dragon's place (glass, IOR 1.5, two-sided).
 

@@ -58,6 +58,20 @@ def scene_set(mesh):
     }
 
 
+# Device branches that the scene set above never reaches: the two remaining cameras of CAMERAS on real scenes and a
+# scene with MirrorBRDF(one_way = true).  name -> (scene key or "oneway", camera)
+def branch_cases(sset):
+    ow, ow_cam = scenes.oneway_mirror_scene()
+    return {
+        "hex_cornell": (sset["cornell"][0], CAMERAS["thinlens_hex"]),          # HexagonalApertureSampler + thin lens, src/camera.cpp:21-50,102-107
+        "hex_meshbox": (sset["meshbox"][0], dict(CAMERAS["thinlens_hex"], origin=(0.3, 0.2, -2.8))),
+        "nolens_box": (sset["box"][0], CAMERAS["aperture_no_lens"]),           # aperture sample without a focal plane, src/camera.cpp:93-99,109
+        "nolens_advanced": (sset["advanced"][0], CAMERAS["aperture_no_lens"]),
+        "oneway": (ow, ow_cam),                                                # MirrorBRDF(true), src/scene/propagation.cpp:178-217
+        "oneway_hex": (ow, dict(CAMERAS["thinlens_hex"], origin=(0.2, 0.1, -2.6), look_at=(0, -0.1, 0))),
+    }
+
+
 def demo_mesh(mesh):
     # the demo places the dragon with a different transform (demo/main.cpp:141-144): half the size, shifted
     mpos, mnrm = mesh

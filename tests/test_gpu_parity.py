@@ -79,6 +79,31 @@ def test_pixels(gpu_scenes, sset, name, tag):
     assert_bits_equal(img[g["ys"][single], g["xs"][single]], g["rgba"][single], "pixel value")
 
 
+BRANCHES = ["hex_cornell", "hex_meshbox", "nolens_box", "nolens_advanced", "oneway", "oneway_hex"]
+
+
+@pytest.mark.parametrize("name", BRANCHES)
+def test_branch_pixels(sset, name):
+    """The device branches no other scene reaches -- HexagonalApertureSampler (src/camera.cpp:21-50), an aperture without a focal plane
+    (camera.cpp:93-99,109) and MirrorBRDF(one_way = true) (src/scene/propagation.cpp:178-217) -- against values and engine states
+    recorded from the compiled reference (tests/golden/branch_*.npz)."""
+    from tests.cases import branch_cases
+    g = golden("branch_" + name)
+    desc, cam = branch_cases(sset)[name]
+    sc = binding.Scene(desc)
+    try:
+        for tag in "abc":
+            xs, ys = g[tag + "_xs"], g[tag + "_ys"]
+            img, st = sc.process_item(cam, opt_from(g[tag + "_options"]), binding.pixel_streams(xs, ys, g[tag + "_states"]))
+            assert_bits_equal(st, g[tag + "_states_out"], "engine state after the pixel (draw count)")
+            key = ys.astype(np.int64) * 65536 + xs
+            _, first, counts = np.unique(key, return_index=True, return_counts=True)
+            single = first[counts == 1]
+            assert_bits_equal(img[ys[single], xs[single]], g[tag + "_rgba"][single], "pixel value")
+    finally:
+        sc.close()
+
+
 def _tile_stream(x, y, w, h, seed):
     s = np.zeros(1, dtype=binding.STREAM_DTYPE)
     s["x"], s["y"], s["w"], s["h"], s["rng_state"] = x, y, w, h, binding.seed_to_state(seed)
@@ -250,41 +275,108 @@ def test_post_processing_full_frame(gpu_scenes, sset, oracle_lib):
     assert_bits_equal(binding.post_process(frame, 2, 1.0)[lit], frame[lit], "gamma 1")
 
 
-@pytest.mark.parametrize("which,spp_min,spp_max", [("cornell", 16, 16), ("mesh80k", 8, 8), ("cornell_adaptive", 4, 24), ("mesh7m", 4, 4)])
-def test_full_size_frame_sampled_against_oracle(sset, oracle_lib, which, spp_min, spp_max):
-    """BASELINE.json's frame size (1024 x 1024, one stream per pixel = 1 M streams in flight, suspended walks, sample overlap, two stream
-    groups for the LDS-resident scene) checked where the oracle can follow: 3000 random pixels rendered by the CPU oracle with the same
-    per-pixel engines must equal the frame's pixels bit for bit.  Also: the frame is reproducible, and the sum of its four quadrants
-    rendered as separate jobs (disjoint tile sets) reproduces it exactly."""
-    if which.startswith("cornell"):
-        desc, cam = sset["cornell"]
-        cam = dict(cam, aspect_ratio=-1.0)
-    else:
-        # mesh7m is bench.py's default workload itself: 7.2 M triangles, a 30-level tree built on the device, walks that outgrow the
-        # LDS window of the traversal stack and spill to HBM
-        side = 1900 if which == "mesh7m" else 200
-        desc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(side, side, scenes.DRAGON_BOX_TRANSFORM))
-    w = h = 1024
-    opt = scenes.options(w, h, spp_min, spp_max)
+@pytest.fixture(scope="module")
+def mesh7m(oracle_lib):
+    """bench.py's default workload itself: DragonBox with the 7.2 M-triangle stand-in mesh, a 30-level tree built on the device, walks that
+    outgrow the LDS window of the traversal stack -- on the GPU and in the CPU oracle (same arrays)."""
+    desc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(1900, 1900, scenes.DRAGON_BOX_TRANSFORM))
     scene = binding.Scene(desc)
-    try:
-        frame = scene.process_job(cam, opt, base_seed=77)
-        rng = np.random.default_rng(5)
-        xs, ys = rng.integers(0, w, 3000).astype(np.int32), rng.integers(0, h, 3000).astype(np.int32)
-        states = np.array([binding.seed_to_state(binding.pixel_seed(77, int(x), int(y))) for x, y in zip(xs, ys)], np.uint64)
-        want, _ = oracle_lib.scene_create(desc).render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=16)
-        assert_bits_equal(frame[ys, xs], want[ys, xs], "sampled pixels of the full-size frame")
-        assert_bits_equal(scene.process_job(cam, opt, base_seed=77), frame, "same job twice")
+    handle = oracle_lib.scene_create(desc)
+    yield desc, cam, scene, handle
+    scene.close()
+    handle.close()
+
+
+def _check_frame_against_oracle(scene, handle, cam, opt, seed, n_pixels=3000, quadrants=True):
+    """3000 random pixels rendered by the CPU oracle with the same per-pixel engines must equal the frame's pixels bit for bit; the frame is
+    reproducible; the sum of its four quadrants rendered as separate jobs (disjoint tile sets) reproduces it exactly."""
+    w, h = opt["image_width"], opt["image_height"]
+    frame = scene.process_job(cam, opt, base_seed=seed)
+    rng = np.random.default_rng(5)
+    xs, ys = rng.integers(0, w, n_pixels).astype(np.int32), rng.integers(0, h, n_pixels).astype(np.int32)
+    states = np.array([binding.seed_to_state(binding.pixel_seed(seed, int(x), int(y))) for x, y in zip(xs, ys)], np.uint64)
+    want, _ = handle.render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=16)
+    assert_bits_equal(frame[ys, xs], want[ys, xs], "sampled pixels of the full-size frame")
+    assert_bits_equal(scene.process_job(cam, opt, base_seed=seed), frame, "same job twice")
+    if quadrants:
         tiles = binding.job_tiles(w, h)
         parts = np.zeros_like(frame)
         for qx in (0, 1):
             for qy in (0, 1):
-                mine = tiles[(tiles["x"] // 512 == qx) & (tiles["y"] // 512 == qy)]
-                img = scene.process_job(cam, opt, base_seed=77, tiles=mine)
-                parts += img
+                mine = tiles[(tiles["x"] // (w // 2) == qx) & (tiles["y"] // (h // 2) == qy)]
+                parts += scene.process_job(cam, opt, base_seed=seed, tiles=mine)
         assert_bits_equal(parts, frame, "four quadrant jobs add up to the frame")
+    return frame
+
+
+@pytest.mark.parametrize("which,spp_min,spp_max", [("cornell", 16, 16), ("mesh80k", 8, 8), ("cornell_adaptive", 4, 24), ("dragons16_80k", 8, 8)])
+def test_full_size_frame_sampled_against_oracle(sset, oracle_lib, which, spp_min, spp_max):
+    """BASELINE.json's frame size (1024 x 1024, one stream per pixel = 1 M streams in flight) checked where the oracle can follow.
+    dragons16_80k is configs[4] at 16 x 79,600 = 1.27 M triangles (the bench runs it at 16 x 7.2 M)."""
+    if which.startswith("cornell"):
+        desc, cam = sset["cornell"]
+        cam = dict(cam, aspect_ratio=-1.0)
+    elif which == "dragons16_80k":
+        desc, cam = scenes.dragon_grid_scene(*scenes.bumpy_sphere_mesh(200, 200, scenes.DRAGON_BOX_TRANSFORM), grid=4)
+    else:
+        desc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(200, 200, scenes.DRAGON_BOX_TRANSFORM))
+    scene = binding.Scene(desc)
+    handle = oracle_lib.scene_create(desc)
+    try:
+        _check_frame_against_oracle(scene, handle, cam, scenes.options(1024, 1024, spp_min, spp_max), 77)
     finally:
         scene.close()
+        handle.close()
+
+
+def test_mesh7m_frame(mesh7m):
+    """configs[2] at frame size: the 7.2 M-triangle DragonBox, 1024 x 1024, 4 spp, sampled against the oracle."""
+    desc, cam, scene, handle = mesh7m
+    _check_frame_against_oracle(scene, handle, cam, scenes.options(1024, 1024, 4, 4), 77)
+
+
+@pytest.mark.parametrize("w,spp,n_pixels", [(1024, 256, 1024), (2048, 4096, 24)])
+def test_mesh7m_long_chains(mesh7m, w, spp, n_pixels):
+    """configs[2] / configs[3] per pixel: 256-sample (4096-sample) chains on the big mesh as processItem streams with given engines --
+    pixel value AND engine state afterwards (= the exact number of draws of every path of the chain) against the oracle."""
+    desc, cam, scene, handle = mesh7m
+    opt = scenes.options(w, w, spp, spp)
+    rng = np.random.default_rng(w + spp)
+    # half of the pixels anywhere, half inside the mesh's silhouette (long glass paths, suspended walks)
+    xs = np.concatenate([rng.integers(0, w, n_pixels // 2), rng.integers(int(0.36 * w), int(0.64 * w), n_pixels - n_pixels // 2)]).astype(np.int32)
+    ys = np.concatenate([rng.integers(0, w, n_pixels // 2), rng.integers(int(0.36 * w), int(0.64 * w), n_pixels - n_pixels // 2)]).astype(np.int32)
+    keep = np.unique(ys.astype(np.int64) * 65536 + xs, return_index=True)[1]
+    xs, ys = xs[keep], ys[keep]
+    states = rng.integers(1, 2**63, len(xs)).astype(np.uint64)
+    img, after = scene.process_item(cam, opt, binding.pixel_streams(xs, ys, states))
+    want, want_after = handle.render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=16)
+    assert_bits_equal(img[ys, xs], want[ys, xs], "pixel values after %d-sample chains" % spp)
+    assert_bits_equal(after, want_after, "engine states after %d-sample chains" % spp)
+    assert (img[ys, xs][:, 3] == 1).mean() > 0.5
+
+
+def test_mesh7m_c4_frame_and_rank_replay(mesh7m):
+    """BASELINE.json configs[3] -- the dragon at 2048 x 2048 = 4096 tiles, sharded over 8 GPUs -- at 2 spp: the frame against oracle-sampled
+    pixels, and the frame assembled from the 8 ranks' tile sets (played one after the other on this GPU with sharding.py's own split and
+    gather indices) against the single-rank frame, bit for bit."""
+    from cpupathtrace_amd import sharding
+    desc, cam, scene, handle = mesh7m
+    side, world = 2048, 8
+    opt = scenes.options(side, side, 2, 2)
+    full = _check_frame_against_oracle(scene, handle, cam, opt, 21, n_pixels=2000, quadrants=False)
+    tiles = binding.job_tiles(side, side)
+    assert len(tiles) == 4096
+    assembled = np.zeros_like(full).reshape(-1, 4)
+    covered = np.zeros(side * side, np.int32)
+    for rank in range(world):
+        mine = sharding.local_tiles(tiles, rank, world)
+        assert len(mine) == 512
+        img = scene.process_job(cam, opt, base_seed=21, tiles=mine).reshape(-1, 4)
+        idx = sharding.pixel_indices(mine, side)
+        assembled[idx] = img[idx]
+        covered[idx] += 1
+    assert (covered == 1).all()
+    assert_bits_equal(assembled.reshape(full.shape), full, "2048x2048 frame assembled from 8 ranks")
 
 
 def test_two_level_walk_matches(sset, oracle_lib):

@@ -136,6 +136,35 @@ def test_pixels(oracle_lib, sset, name, tag):
     assert_bits_equal(st, g["states_out"], "engine state after the pixel")
 
 
+BRANCHES = ["hex_cornell", "hex_meshbox", "nolens_box", "nolens_advanced", "oneway", "oneway_hex"]
+
+
+def _unique_pixels(xs, ys):
+    key = ys.astype(np.int64) * 65536 + xs
+    _, first, counts = np.unique(key, return_index=True, return_counts=True)
+    return first[counts == 1]
+
+
+@pytest.mark.parametrize("name", BRANCHES)
+def test_branches(oracle_lib, sset, name):
+    """Hexagonal aperture, aperture without a lens, one-way mirror: single paths and 1x1 items recorded from the compiled reference."""
+    from tests.cases import branch_cases
+    g = golden("branch_" + name)
+    sc, cam = branch_cases(sset)[name]
+    h = oracle_lib.scene_create(sc)
+    rgba, col, st = h.get_sample(cam, opt_from([64, 64, 16, 64]), g["sample_xy"], g["sample_states"])
+    assert_bits_equal(rgba, g["sample_rgba"], "getSample rgba")
+    assert_bits_equal(col, g["sample_collected"], "getSample collected")
+    assert_bits_equal(st, g["sample_states_out"], "getSample draw count")
+    assert 0.3 < g["sample_collected"].mean(), "the camera looks at the scene"
+    for tag in "abc":
+        xs, ys = g[tag + "_xs"], g[tag + "_ys"]
+        img, st = h.render_streams(cam, opt_from(g[tag + "_options"]), oracle.pixel_streams(xs, ys, g[tag + "_states"]), n_threads=4)
+        single = _unique_pixels(xs, ys)
+        assert_bits_equal(img[ys[single], xs[single]], g[tag + "_rgba"][single], "pixel")
+        assert_bits_equal(st, g[tag + "_states_out"], "engine state after the pixel")
+
+
 def _tile(h, cam, opt, x, y, w, hh, seed):
     s = np.zeros(1, dtype=oracle.STREAM_DTYPE)
     s["x"], s["y"], s["w"], s["h"], s["rng_state"] = x, y, w, hh, oracle.seed_to_state(seed)

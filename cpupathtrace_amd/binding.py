@@ -21,7 +21,7 @@ PT_OK = 0
 ERRORS = {1: "PT_ERR_INVALID", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR_HIP", 4: "PT_ERR_UNSUPPORTED", 5: "PT_ERR_NOMEM"}
 
 EXPORTS = ["pt_device_count", "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_scene_info", "pt_scene_emissive", "pt_scene_bvh_dump", "pt_intersect_batch",
-           "pt_render_streams", "pt_render_tiles", "pt_render_tiles_device", "pt_job_tiles", "pt_pixel_seed", "pt_rng_seed_to_state", "pt_post_process", "pt_post_process_device"]
+           "pt_render_streams", "pt_render_tiles", "pt_render_tiles_progress", "pt_render_tiles_device", "pt_job_tiles", "pt_pixel_seed", "pt_rng_seed_to_state", "pt_post_process", "pt_post_process_device"]
 
 
 class PtError(RuntimeError):

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -190,9 +191,33 @@ struct pt_scene {
     hipStream_t group_stream[PT_MAX_GROUPS] = {};
     uint32_t concurrent_streams = 0; // group streams found to run side by side (pick_concurrent_streams)
 
+    // One render call at a time per scene: the workspace below is shared by every entry point (processItem may be called from several
+    // threads on one const Scene, reference worker.h:66-69 / src/worker.cpp:328-362: such callers are serialised here).
+    std::mutex render_mutex;
+
+    // workspace of the persistent path kernel (pt_path.hip)
+    bool use_path = true;
+    PtPathConfig path_cfg{};
+    int path_blocks_per_cu = 0;
+    uint32_t path_slots = 0, path_waves = 0, path_cap = 0;
+    DevBuf<uint32_t> sl_stream, sl_nee_mask, pull_counter, tile_left;
+    DevBuf<int4> sl_rect, st_rect;
+    DevBuf<int32_t> sl_cursor, sl_path_length;
+    DevBuf<uint64_t> sl_rng, st_rng;
+    DevBuf<F4> sl_ray_o, sl_ray_d, sl_spectrum, sl_out, sl_nee, lq_ray_o, lq_ray_d;
+    DevBuf<double> sl_divisor, sl_bounce_pd;
+    DevBuf<PtEstimator> sl_est;
+    DevBuf<PtCandidate> sl_cand;
+    DevBuf<uint2> path_spill, closest_out;
+    DevBuf<unsigned long long> path_wave_counters;
+    uint32_t *host_tiles_done = nullptr; // pinned: tiles finished so far, written by the kernel (progress callback)
+
     ~pt_scene() {
         if(host_counters != nullptr) {
             (void)hipHostFree(host_counters);
+        }
+        if(host_tiles_done != nullptr) {
+            (void)hipHostFree(host_tiles_done);
         }
         for(hipEvent_t e : check_event) {
             if(e != nullptr) {
@@ -781,6 +806,203 @@ int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, 
     return PT_OK;
 }
 
+// ---- the persistent path kernel (pt_path.hip): one launch per render call ---------------------------------------------------------------
+
+struct Event {
+    hipEvent_t e = nullptr;
+    hipError_t create(unsigned flags = hipEventDefault) { return hipEventCreateWithFlags(&e, flags); }
+    ~Event() {
+        if(e != nullptr) {
+            (void)hipEventDestroy(e);
+        }
+    }
+};
+
+
+int setup_path(pt_scene *s) {
+    PtPathConfig &cfg = s->path_cfg;
+    if(cfg.rows != 0) {
+        return PT_OK;
+    }
+    cfg.in_lds = (s->dev.n_lds_pairs == s->dev.n_pairs && s->dev.n_lds_tris == s->dev.n_tris && s->dev.n_lds_pairs + s->dev.n_lds_tris > 0) ? 1 : 0;
+    // walks of a tree of at most 8 levels never leave an 8-entry window
+    int stack_lds = env_int("PT_STACK_LDS", s->depth <= 8 ? 8 : 16);
+    cfg.stack_lds = stack_lds == 8 ? 8 : 16;
+    cfg.rows = std::min(std::max(env_int("PT_ROWS", 4), 1), PT_MAX_ROWS);
+    cfg.lds_bytes = pt_path_lds_bytes(cfg.stack_lds, cfg.rows, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.n_lds_tris : 0U);
+    const int per_cu = pt_path_blocks_per_cu(cfg.stack_lds, cfg.in_lds, cfg.lds_bytes);
+    const int limit = env_int("PT_BLOCKS_PER_CU", 0);
+    s->path_blocks_per_cu = (limit > 0 && limit < per_cu) ? limit : per_cu;
+    cfg.spill_depth = s->depth > static_cast<uint32_t>(cfg.stack_lds) ? s->depth - static_cast<uint32_t>(cfg.stack_lds) : 1U;
+    cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 12), 1), 64);
+    cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
+    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 4), 1), 64);
+    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 8), 1), 64);
+    if(env_int("PT_DEBUG", 0) != 0) {
+        std::fprintf(stderr, "[pt] path kernel: %d CUs x %d workgroups, %d rows of slots per wavefront, stack_lds %d, scene %s, lds %zu B, spill depth %u\n", s->cu_count,
+                     s->path_blocks_per_cu, cfg.rows, cfg.stack_lds, cfg.in_lds ? "in LDS" : "in HBM", cfg.lds_bytes, cfg.spill_depth);
+    }
+    return PT_OK;
+}
+
+// Grid and slot rows for n streams, and the buffers they need.
+int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
+    int rc = setup_path(s);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    PtPathConfig cfg = s->path_cfg;
+    const uint32_t max_grid = static_cast<uint32_t>(s->cu_count) * static_cast<uint32_t>(s->path_blocks_per_cu);
+    const uint32_t grid = std::max<uint32_t>(1U, std::min<uint32_t>(max_grid, (n + 255U) / 256U)); // every wavefront gets at least one row of 64 streams
+    const uint32_t waves = grid * 4U;
+    const uint32_t rows = std::min<uint32_t>(static_cast<uint32_t>(cfg.rows), std::max<uint32_t>(1U, (n + waves * 64U - 1U) / (waves * 64U)));
+    const uint32_t total = waves * rows * 64U;
+    const uint32_t rays_per_slot = 1U + s->dev.n_lights + s->dev.n_object_samples;
+    const uint32_t cap = rows * 64U * rays_per_slot;
+    cfg.grid = static_cast<int>(grid);
+    cfg.rows = static_cast<int>(rows);
+    PT_HIP(s->sl_stream.ensure(total));
+    PT_HIP(s->sl_rect.ensure(total));
+    PT_HIP(s->sl_cursor.ensure(total));
+    PT_HIP(s->sl_rng.ensure(total));
+    PT_HIP(s->sl_ray_o.ensure(total));
+    PT_HIP(s->sl_ray_d.ensure(total));
+    PT_HIP(s->sl_spectrum.ensure(total));
+    PT_HIP(s->sl_out.ensure(total));
+    PT_HIP(s->sl_divisor.ensure(total));
+    PT_HIP(s->sl_bounce_pd.ensure(total));
+    PT_HIP(s->sl_path_length.ensure(total));
+    PT_HIP(s->sl_nee_mask.ensure(total));
+    PT_HIP(s->sl_nee.ensure(static_cast<size_t>(total) * std::max<uint32_t>(rays_per_slot - 1U, 1U)));
+    PT_HIP(s->sl_est.ensure(total));
+    PT_HIP(s->sl_cand.ensure(static_cast<size_t>(total) * PT_MAX_CANDIDATES));
+    PT_HIP(s->lq_ray_o.ensure(static_cast<size_t>(waves) * cap));
+    PT_HIP(s->lq_ray_d.ensure(static_cast<size_t>(waves) * cap));
+    PT_HIP(s->path_spill.ensure(static_cast<size_t>(waves) * 64U * cfg.spill_depth));
+    PT_HIP(s->path_wave_counters.ensure(static_cast<size_t>(waves) * 8U));
+    PT_HIP(s->pull_counter.ensure(64));
+    PT_HIP(s->counters.ensure(PT_MAX_GROUPS));
+    cfg.spill = s->path_spill.ptr;
+    cfg.wave_counters = s->path_wave_counters.ptr;
+    s->path_slots = total;
+    s->path_waves = waves;
+    s->path_cap = cap;
+    *out_cfg = cfg;
+    return PT_OK;
+}
+
+// Render the streams described by T (device pointers) with one launch on the scene's stream.  With a progress function the host polls
+// the count of finished tiles (pinned memory, written by the kernel) while the launch runs and reports every step from the calling thread.
+int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStreams T, float4 *d_image, pt_stats *stats, pt_progress_fn progress, void *progress_user) {
+    PtPathConfig cfg;
+    int rc = ensure_path_workspace(s, T.n, &cfg);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    hipStream_t st = s->stream;
+    PtSlots S{};
+    S.total = s->path_slots;
+    S.stream = s->sl_stream.ptr;
+    S.rect = s->sl_rect.ptr;
+    S.cursor = s->sl_cursor.ptr;
+    S.rng = s->sl_rng.ptr;
+    S.ray_o = reinterpret_cast<float4 *>(s->sl_ray_o.ptr);
+    S.ray_d = reinterpret_cast<float4 *>(s->sl_ray_d.ptr);
+    S.spectrum = reinterpret_cast<float4 *>(s->sl_spectrum.ptr);
+    S.out = reinterpret_cast<float4 *>(s->sl_out.ptr);
+    S.divisor = s->sl_divisor.ptr;
+    S.bounce_pd = s->sl_bounce_pd.ptr;
+    S.path_length = s->sl_path_length.ptr;
+    S.nee_mask = s->sl_nee_mask.ptr;
+    S.nee = reinterpret_cast<float4 *>(s->sl_nee.ptr);
+    S.est = s->sl_est.ptr;
+    S.cand = s->sl_cand.ptr;
+    PtLocalQueue Q{};
+    Q.ray_o = reinterpret_cast<float4 *>(s->lq_ray_o.ptr);
+    Q.ray_d = reinterpret_cast<float4 *>(s->lq_ray_d.ptr);
+    Q.cap = s->path_cap;
+    T.next = s->pull_counter.ptr;
+    T.tile_left = nullptr;
+    T.tiles_done = nullptr;
+    if(progress != nullptr && T.rect == nullptr && T.n_tiles > 0) {
+        if(s->host_tiles_done == nullptr) {
+            PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->host_tiles_done), 64, hipHostMallocDefault));
+        }
+        *s->host_tiles_done = 0;
+        T.tiles_done = s->host_tiles_done;
+        T.tile_left = s->tile_left.ptr; // filled by the caller (pixels per tile)
+    }
+    PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters), st));
+    PT_HIP(hipMemsetAsync(s->pull_counter.ptr, 0, 64 * sizeof(uint32_t), st));
+    PT_HIP(hipMemsetAsync(s->path_wave_counters.ptr, 0, static_cast<size_t>(s->path_waves) * 8U * sizeof(unsigned long long), st));
+    Event ev_begin, ev_end;
+    PT_HIP(ev_begin.create());
+    PT_HIP(ev_end.create());
+    PT_HIP(hipEventRecord(ev_begin.e, st));
+    pt_launch_path(st, s->dev, cam, opt, S, T, Q, cfg, d_image, s->counters.ptr);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipEventRecord(ev_end.e, st));
+    if(T.tiles_done != nullptr) {
+        const int total = static_cast<int>(T.n_tiles);
+        int reported = 0;
+        for(;;) {
+            const hipError_t q = hipEventQuery(ev_end.e);
+            const int done = std::min(static_cast<int>(*static_cast<volatile uint32_t *>(s->host_tiles_done)), total);
+            while(reported < done) {
+                progress(++reported, total, progress_user);
+            }
+            if(q == hipSuccess) {
+                break;
+            }
+            if(q != hipErrorNotReady) {
+                return fail(PT_ERR_HIP, std::string("path kernel: ") + hipGetErrorString(q));
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(500));
+        }
+        const int done = std::min(static_cast<int>(*static_cast<volatile uint32_t *>(s->host_tiles_done)), total);
+        while(reported < done) {
+            progress(++reported, total, progress_user);
+        }
+    }
+    if(stats != nullptr) {
+        PT_HIP(hipEventSynchronize(ev_end.e));
+        float ms = 0.0F;
+        PT_HIP(hipEventElapsedTime(&ms, ev_begin.e, ev_end.e));
+        std::vector<unsigned long long> slots(static_cast<size_t>(s->path_waves) * 8U);
+        PT_HIP(hipMemcpy(slots.data(), s->path_wave_counters.ptr, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kcycles[3] = {0, 0, 0};
+        for(size_t i = 0; i < slots.size(); i++) {
+            // (a PT_PATH_TIMING build packs kilo-cycle totals into the high words of three slots; they are zero otherwise)
+            const size_t k = i & 7U;
+            sum[k] += (k >= 3 && k <= 5) ? (slots[i] & 0xffffffffULL) : slots[i];
+            if(k >= 3 && k <= 5) {
+                kcycles[k - 3] += slots[i] >> 32;
+            }
+        }
+        if(kcycles[0] != 0 && env_int("PT_DEBUG", 0) != 0) {
+            std::fprintf(stderr, "[pt] wave time: %.1f %% in shading passes, %.1f %% in traversal bursts (of the waves' lifetimes; %llu kilo-cycles in all)\n",
+                         100.0 * static_cast<double>(kcycles[2]) / static_cast<double>(kcycles[0]), 100.0 * static_cast<double>(kcycles[1]) / static_cast<double>(kcycles[0]), kcycles[0]);
+        }
+        stats->node_visits = sum[0];
+        stats->leaf_tests = sum[1];
+        stats->rays_traced = sum[2];
+        stats->shadow_rays_traced = sum[3];
+        stats->samples = sum[6];
+        stats->vertices = sum[7];
+        stats->iterations = 1;
+        stats->trace_ms = ms;
+        stats->trace_busy_ms = ms;
+        stats->shade_ms = 0.0;
+        stats->total_ms = ms;
+        stats->groups = 1;
+        if(env_int("PT_DEBUG", 0) != 0) {
+            std::fprintf(stderr, "[pt] path kernel: %.2f ms, grid %d x 256, %d rows; wave steps %llu (%.1f lanes of 64 busy per step), shading passes %llu, rays %llu\n", ms, cfg.grid,
+                         cfg.rows, sum[4], sum[4] ? static_cast<double>(sum[0] + sum[1]) / static_cast<double>(sum[4]) : 0.0, sum[5], sum[2]);
+        }
+    }
+    return PT_OK;
+}
+
 uint32_t choose_groups(pt_scene *s, uint32_t n) {
     // Measured: three groups of streams on three HIP streams, so that one group's shading (and the thin end of its
     // traversal launches) overlaps the others' traversal.  Scenes that live in LDS: +23 % (two groups +13 %, four -3 %).  HBM-resident
@@ -959,7 +1181,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         PT_HIP(up(raw_sph, d->sph, 4 * static_cast<size_t>(d->n_spheres)));
         PT_HIP(up(raw_sph_mat, d->sph_material, d->n_spheres));
         PT_HIP(up(raw_sph_obj, s->sph_obj.data(), d->n_spheres));
-        PT_HIP(s->tris.ensure(3 * static_cast<size_t>(d->n_triangles)));
+        PT_HIP(s->tris.ensure(3 * static_cast<size_t>(d->n_triangles) + 1)); // + 1: a traversal step reads 64 bytes of a 48-byte record
         PT_HIP(s->tri_shade.ensure(8 * static_cast<size_t>(d->n_triangles)));
         PT_HIP(s->spheres.ensure(d->n_spheres));
         PT_HIP(s->sph_meta.ensure(d->n_spheres));
@@ -1078,7 +1300,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         s->build_ms[0] = ms_since(t_begin);
         const auto t_upload = clock::now();
 
-        std::vector<F4> tris(3 * static_cast<size_t>(d->n_triangles)), shade(8 * static_cast<size_t>(d->n_triangles), F4{0.0F, 0.0F, 0.0F, 0.0F});
+        std::vector<F4> tris(3 * static_cast<size_t>(d->n_triangles) + 1, F4{0.0F, 0.0F, 0.0F, 0.0F}), shade(8 * static_cast<size_t>(d->n_triangles), F4{0.0F, 0.0F, 0.0F, 0.0F});
         for(uint32_t t = 0; t < d->n_triangles; t++) {
             const float *p = d->tri_pos + 9 * static_cast<size_t>(t);
             const Vec3 a = ld(p), b = ld(p + 3), c = ld(p + 6);
@@ -1264,6 +1486,9 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     if(rc != PT_OK) {
         return rc;
     }
+    if(const char *kernel = std::getenv("PT_KERNEL")) {
+        s->use_path = std::strcmp(kernel, "wavefront") != 0; // A/B against round 1's two-kernel wavefront loop
+    }
     s->build_ms[3] = ms_since(t_rest);
     if(env_int("PT_DEBUG", 0) != 0) {
         std::fprintf(stderr, "[pt] scene build (%s): %u objects, %u pair records, depth %u; host preparation %.1f ms, upload %.1f ms, device tree %.1f ms, rest %.1f ms\n",
@@ -1399,8 +1624,34 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
     if(n > 0x7fffffffULL) {
         return fail(PT_ERR_INVALID, "too many rays in one batch");
     }
+    std::lock_guard<std::mutex> lock(s->render_mutex);
     PT_HIP(hipSetDevice(s->device));
     const uint32_t n32 = static_cast<uint32_t>(n);
+    if(s->use_path) {
+        int rc = setup_path(s);
+        if(rc != PT_OK) {
+            return rc;
+        }
+        PtPathConfig cfg = s->path_cfg;
+        PT_HIP(s->batch_rays.ensure(6 * n));
+        PT_HIP(s->closest_out.ensure(n));
+        PT_HIP(s->path_spill.ensure(((n + 255) / 256) * 256 * cfg.spill_depth));
+        cfg.spill = s->path_spill.ptr;
+        hipStream_t st = s->stream;
+        PT_HIP(hipMemcpyAsync(s->batch_rays.ptr, rays, 6 * n * sizeof(float), hipMemcpyHostToDevice, st));
+        pt_launch_closest(st, s->dev, s->batch_rays.ptr, n32, s->closest_out.ptr, cfg);
+        PT_HIP(hipGetLastError());
+        std::vector<uint2> hits(n);
+        PT_HIP(hipMemcpyAsync(hits.data(), s->closest_out.ptr, n * sizeof(uint2), hipMemcpyDeviceToHost, st));
+        PT_HIP(hipStreamSynchronize(st));
+        for(size_t i = 0; i < n; i++) {
+            const float t = from_bits(hits[i].x);
+            const uint32_t ref = hits[i].y;
+            out_t[i] = t;
+            out_obj[i] = (t < 0.0F || ref == PT_REF_NONE) ? -1 : static_cast<int32_t>((ref & PT_REF_SPHERE) ? s->sph_obj[ref & PT_REF_INDEX] : s->tri_obj[ref & PT_REF_INDEX]);
+        }
+        return PT_OK;
+    }
     int rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples);
     if(rc != PT_OK) {
         return rc;
@@ -1482,16 +1733,40 @@ int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_opti
         rects[i] = make_int4(t.x, t.y, t.w, t.h);
         states[i] = t.rng_state;
     }
+    std::lock_guard<std::mutex> lock(s->render_mutex);
     PT_HIP(hipSetDevice(s->device));
     const uint32_t n32 = static_cast<uint32_t>(n);
+    const size_t pixels = static_cast<size_t>(options->image_width) * static_cast<size_t>(options->image_height);
+    PT_HIP(s->image.ensure(pixels));
+    hipStream_t st = s->stream;
+    if(s->use_path) {
+        PT_HIP(s->st_rect.ensure(n));
+        PT_HIP(s->st_rng.ensure(n));
+        // pixels not covered by a stream keep the caller's values
+        PT_HIP(hipMemcpyAsync(s->image.ptr, out_image, pixels * sizeof(F4), hipMemcpyHostToDevice, st));
+        PT_HIP(hipMemcpyAsync(s->st_rect.ptr, rects.data(), n * sizeof(int4), hipMemcpyHostToDevice, st));
+        PT_HIP(hipMemcpyAsync(s->st_rng.ptr, states.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        PtStreams T{};
+        T.n = n32;
+        T.rect = s->st_rect.ptr;
+        T.rng = s->st_rng.ptr;
+        rc = run_path(s, cam, opt, T, reinterpret_cast<float4 *>(s->image.ptr), stats, nullptr, nullptr);
+        if(rc != PT_OK) {
+            (void)hipStreamSynchronize(st); // rects / states are this function's vectors
+            return rc;
+        }
+        PT_HIP(hipMemcpyAsync(out_image, s->image.ptr, pixels * sizeof(F4), hipMemcpyDeviceToHost, st));
+        if(out_states != nullptr) {
+            PT_HIP(hipMemcpyAsync(out_states, s->st_rng.ptr, n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        }
+        PT_HIP(hipStreamSynchronize(st));
+        return PT_OK;
+    }
     const uint32_t groups = choose_groups(s, n32);
     rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples, groups);
     if(rc != PT_OK) {
         return rc;
     }
-    const size_t pixels = static_cast<size_t>(options->image_width) * static_cast<size_t>(options->image_height);
-    PT_HIP(s->image.ensure(pixels));
-    hipStream_t st = s->stream;
     // pixels not covered by a stream keep the caller's values
     PT_HIP(hipMemcpyAsync(s->image.ptr, out_image, pixels * sizeof(F4), hipMemcpyHostToDevice, st));
     PT_HIP(hipMemcpyAsync(s->rect.ptr, rects.data(), n * sizeof(int4), hipMemcpyHostToDevice, st));
@@ -1510,7 +1785,7 @@ int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_opti
 }
 
 static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles, uint64_t base_seed,
-                             float4 *d_image, pt_stats *stats) {
+                             float4 *d_image, pt_stats *stats, pt_progress_fn progress = nullptr, void *progress_user = nullptr) {
     PtDevOptions opt;
     int rc = derive_options(options, &opt);
     if(rc != PT_OK) {
@@ -1529,6 +1804,36 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
         return fail(PT_ERR_INVALID, "too many pixels in one call");
     }
     const uint32_t n32 = static_cast<uint32_t>(total);
+    if(s->use_path) {
+        // stream i = pixel i of the tiles laid end to end; the kernel derives rectangle and engine from the tile table
+        std::vector<int4> rects(n_tiles);
+        std::vector<uint32_t> offsets(n_tiles), left(n_tiles);
+        uint64_t at = 0;
+        for(size_t k = 0; k < n_tiles; k++) {
+            const pt_tile &t = tiles[k];
+            rects[k] = make_int4(t.x, t.y, t.w, t.h);
+            offsets[k] = static_cast<uint32_t>(at);
+            left[k] = static_cast<uint32_t>(t.w) * static_cast<uint32_t>(t.h);
+            at += left[k];
+        }
+        PT_HIP(s->tiles.ensure(n_tiles));
+        PT_HIP(s->tile_offset.ensure(n_tiles));
+        hipStream_t st = s->stream;
+        PT_HIP(hipMemcpyAsync(s->tiles.ptr, rects.data(), n_tiles * sizeof(int4), hipMemcpyHostToDevice, st));
+        PT_HIP(hipMemcpyAsync(s->tile_offset.ptr, offsets.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        if(progress != nullptr) {
+            PT_HIP(s->tile_left.ensure(n_tiles));
+            PT_HIP(hipMemcpyAsync(s->tile_left.ptr, left.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        }
+        PT_HIP(hipStreamSynchronize(st)); // the tables are this function's vectors
+        PtStreams T{};
+        T.n = n32;
+        T.tiles = s->tiles.ptr;
+        T.tile_offset = s->tile_offset.ptr;
+        T.n_tiles = static_cast<uint32_t>(n_tiles);
+        T.base_seed = base_seed;
+        return run_path(s, cam, opt, T, d_image, stats, progress, progress_user);
+    }
     const uint32_t groups = choose_groups(s, n32);
     // Stream slots are laid out tile after tile and the stream groups are contiguous ranges of slots: with the tiles in the caller's
     // (row-major) order a group is a horizontal band of the frame.  That is deliberate: the bands differ in cost, so the groups reach
@@ -1561,6 +1866,11 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
 
 int pt_render_tiles(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles, uint64_t base_seed,
                     float *out_image, pt_stats *stats) {
+    return pt_render_tiles_progress(s, camera, options, tiles, n_tiles, base_seed, out_image, stats, nullptr, nullptr);
+}
+
+int pt_render_tiles_progress(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles, uint64_t base_seed,
+                             float *out_image, pt_stats *stats, pt_progress_fn progress, void *progress_user) {
     int rc = check_render_args(s, camera, options);
     if(rc != PT_OK) {
         return rc;
@@ -1574,11 +1884,12 @@ int pt_render_tiles(pt_scene *s, const pt_camera_params *camera, const pt_option
     if(tiles == nullptr || out_image == nullptr) {
         return fail(PT_ERR_INVALID, "null argument");
     }
+    std::lock_guard<std::mutex> lock(s->render_mutex);
     PT_HIP(hipSetDevice(s->device));
     const size_t pixels = static_cast<size_t>(options->image_width) * static_cast<size_t>(options->image_height);
     PT_HIP(s->image.ensure(pixels));
     PT_HIP(hipMemcpyAsync(s->image.ptr, out_image, pixels * sizeof(F4), hipMemcpyHostToDevice, s->stream));
-    rc = render_tiles_impl(s, camera, options, tiles, n_tiles, base_seed, reinterpret_cast<float4 *>(s->image.ptr), stats);
+    rc = render_tiles_impl(s, camera, options, tiles, n_tiles, base_seed, reinterpret_cast<float4 *>(s->image.ptr), stats, progress, progress_user);
     if(rc != PT_OK) {
         return rc;
     }
@@ -1602,19 +1913,19 @@ int pt_render_tiles_device(pt_scene *s, const pt_camera_params *camera, const pt
     if(tiles == nullptr || d_out_image == nullptr) {
         return fail(PT_ERR_INVALID, "null argument");
     }
+    std::lock_guard<std::mutex> lock(s->render_mutex);
     PT_HIP(hipSetDevice(s->device));
     // order after the caller's stream, render on the library's stream, then make the caller's stream wait for it
     hipStream_t caller = static_cast<hipStream_t>(stream);
-    hipEvent_t ev;
-    PT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    PT_HIP(hipEventRecord(ev, caller));
-    PT_HIP(hipStreamWaitEvent(s->stream, ev, 0));
+    Event ev;
+    PT_HIP(ev.create(hipEventDisableTiming));
+    PT_HIP(hipEventRecord(ev.e, caller));
+    PT_HIP(hipStreamWaitEvent(s->stream, ev.e, 0));
     rc = render_tiles_impl(s, camera, options, tiles, n_tiles, base_seed, reinterpret_cast<float4 *>(d_out_image), stats);
     if(rc == PT_OK) {
-        PT_HIP(hipEventRecord(ev, s->stream));
-        PT_HIP(hipStreamWaitEvent(caller, ev, 0));
+        PT_HIP(hipEventRecord(ev.e, s->stream));
+        PT_HIP(hipStreamWaitEvent(caller, ev.e, 0));
     }
-    (void)hipEventDestroy(ev);
     return rc;
 }
 

@@ -100,6 +100,82 @@ void pt_launch_trace(hipStream_t stream, const PtDevScene &scene, PtQueue queue,
 void pt_launch_batch_rays(hipStream_t stream, const float *rays6, uint32_t n, PtQueue queue);
 int pt_trace_blocks_per_cu(int stack_lds, int lds_mode, size_t lds_bytes);
 
+
+// ---- the persistent path kernel (pt_path.hip) ---------------------------------------------------------------------------------------
+// One launch renders a whole set of streams.  Every wavefront of the grid is an independent renderer: it owns `rows` x 64 stream SLOTS,
+// a ray queue of its own and its share of the per-slot path state, and alternates between shading the slots whose rays have come back
+// and tracing the rays that produced -- without ever synchronising with another wavefront.  A slot that has finished its stream pulls
+// the next one from a global counter.
+
+#define PT_MAX_ROWS 8      /* rows of 64 slots per wavefront */
+#define PT_F_STREAM 128u   /* the slot holds a stream (flag bit, next to PT_F_*) */
+
+// Path state of the slots (structure of arrays).  Slot index = (global wave index * rows + row) * 64 + lane, so that every access of a
+// shading pass over one row is one coalesced run of 64 elements.
+struct PtSlots {
+    uint32_t total;        // slots of the whole grid (stride of the `nee` planes)
+    uint32_t *stream;      // stream index held by the slot
+    int4 *rect;            // its WorkItem rectangle
+    int32_t *cursor;       // index of the current pixel inside the rectangle (row-major)
+    uint64_t *rng;         // xorshift state of the stream's engine
+    float4 *ray_o;         // current ray origin; w = contribution_unweighted (worker.cpp:38)
+    float4 *ray_d;         // current ray direction
+    float4 *spectrum;      // sample_spectrum (worker.cpp:41)
+    float4 *out;           // out_spectrum (worker.cpp:42)
+    double *divisor;       // sample_divisor (worker.cpp:39)
+    double *bounce_pd;     // sample_bounce_pd (worker.cpp:40)
+    int32_t *path_length;  // worker.cpp:43
+    uint32_t *nee_mask;    // bit j: light sample j of the last vertex contributes if its shadow ray is unoccluded
+    float4 *nee;           // [PT_MAX_NEE][total] weighed_spectrum of the pending shadow rays (worker.cpp:97)
+    PtEstimator *est;      // per-pixel estimator (worker.cpp:172-192)
+    PtCandidate *cand;     // [total][PT_MAX_CANDIDATES]
+};
+
+// The streams of one render call.  Either explicit (rect + engine state per stream: processItem calls) or the pixels of a tile list, each
+// its own 1x1 stream seeded from (base_seed, x, y) (processJob): then rect and rng are null and stream i is pixel i of the tiles laid end
+// to end.
+struct PtStreams {
+    uint32_t n;
+    const int4 *rect;            // [n] or null
+    uint64_t *rng;               // [n] engine state in, engine state out; or null
+    const int4 *tiles;           // [n_tiles] x, y, w, h
+    const uint32_t *tile_offset; // [n_tiles] first stream of each tile
+    uint32_t n_tiles;
+    uint64_t base_seed;
+    uint32_t *next;              // global pull counter (alone in its cache line)
+    uint32_t *tile_left;         // [n_tiles] pixels of the tile not yet finished, or null: no progress reporting
+    uint32_t *tiles_done;        // HOST-visible count of finished tiles (pinned memory), or null
+};
+
+// Ray queues, one private ring per wavefront: entries [wave * cap, (wave + 1) * cap)
+struct PtLocalQueue {
+    float4 *ray_o;   // origin xyz, w = shadow threshold |to_light| - epsilon (worker.cpp:86) or unused
+    float4 *ray_d;   // direction xyz, w = bits destination: bit 31 = shadow ray, bits 16..19 = light sample, bits 0..15 = slot of the wave
+    uint32_t cap;    // rows * 64 * rays per slot
+};
+
+struct PtPathConfig {
+    int grid;             // workgroups of 256 threads
+    int rows;             // rows of 64 slots per wavefront (<= PT_MAX_ROWS)
+    int stack_lds;        // traversal stack entries per lane kept in LDS
+    uint32_t spill_depth; // further entries per lane in HBM
+    uint2 *spill;
+    size_t lds_bytes;
+    int in_lds;           // whole tree + triangle records staged in LDS (small scenes)
+    int refill_idle;      // idle lanes that make a wavefront refill from its queue (or shade when the queue is empty)
+    int min_ready;        // slots that must be ready before a wavefront with walks in progress stops tracing to shade
+    int burst_steps;      // traversal steps between two looks at the queue
+    int leaf_min;         // lanes that must stand on a leaf before the leaf code runs (while other lanes still have nodes to visit)
+    unsigned long long *wave_counters; // [grid * 4 waves][8] node visits, leaf tests, rays, shadow rays, wave steps, shading passes, samples, vertices
+};
+
+void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams,
+                    PtLocalQueue queue, const PtPathConfig &cfg, float4 *image, PtDevCounters *counters);
+int pt_path_blocks_per_cu(int stack_lds, int in_lds, size_t lds_bytes);
+size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_tris);
+// Scene::getIntersection for n rays (6 floats each): out[i] = (bits t, ref)
+void pt_launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg);
+
 uint64_t pt_host_pixel_seed(uint64_t base_seed, int32_t x, int32_t y);
 
 #endif

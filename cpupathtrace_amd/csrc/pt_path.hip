@@ -1,0 +1,1023 @@
+// pt_path.hip -- the hot path as ONE persistent kernel: per-pixel propagation loop (impl::getSample, src/worker.cpp:26-146), per-pixel
+// estimator (processItem, src/worker.cpp:149-326) and closest-hit / shadow traversal of the reference's BVH
+// (Scene::getIntersection, src/scene/scene.cpp:104-150,210-220).
+//
+// Every wavefront of the grid is an independent renderer.  It owns `rows` x 64 stream SLOTS (a slot = one processItem stream in
+// progress: one engine, one path in flight), a private ring of rays in HBM and a few words per slot in LDS, and runs
+//
+//     loop:  retire finished walks (results -> LDS)
+//            idle lanes?  queue has rays -> hand them out
+//                         queue empty    -> SHADE every slot whose rays have all come back (one pass per row of 64 slots: coalesced
+//                                           path state, exactly the reference's order of draws per stream), which appends new rays
+//            TRACE: a burst of traversal steps for the 64 walks in the lanes
+//
+// until its slots have no stream left and the global stream counter is exhausted.  Nothing is ever synchronised between wavefronts
+// (no grid barrier, no shared queue, no launch boundary): a ray that needs thousands of traversal steps keeps ONE lane busy and makes
+// ONE stream miss a few shading passes, while the other 63 lanes and 255 slots go on -- in the two-kernel wavefront design of round 1
+// every launch lasted as long as its slowest walk and the average wavefront was alive for 48 % of it (profiles/r01_pmc_*).
+// Lanes are not tied to slots: a lane takes the next ray of the wave's queue whatever slot it belongs to, so the traversal runs on
+// compacted, full wavefronts although the streams progress at different speeds.
+//
+// Traversal: the ordered recursion of impl::getChildIntersection restated as an iterative walk that visits exactly the leaves the
+// recursion visits, in the same order:
+//   * at an inner node both child boxes are tested (bounding_box.cpp:38-73); the nearer child is entered first, on equal entry
+//     distances the RIGHT child is the nearer one (scene.cpp:120-121);
+//   * a child is entered only if 0 <= entry < t_max (scene.cpp:124,137), where t_max is the smallest hit distance found so far -- in
+//     the recursion t_max is threaded by value, but at every decision point it equals that global minimum, and the early return of
+//     scene.cpp:129-132 is the same test (close hit < far entry  <=>  far entry >= t_max);
+//   * the far child is parked on a per-lane stack TOGETHER with its entry distance and re-tested against the then-current t_max when
+//     it is popped;
+//   * a leaf reports Object::getIntersection unconditionally (scene.cpp:105-109); among non-negative hits the smallest wins and a
+//     later-visited leaf wins ties (scene.cpp:141-146).
+// Shadow rays (worker.cpp:84-86) only need "is there a visited leaf with 0 <= t < |to_light| - epsilon"; the walk stops at the first
+// such leaf, which cannot change the answer.
+// One traversal step serves inner nodes and leaves alike: every lane fetches the 64-byte record it stands on (a node's two child
+// boxes, or a triangle) with the same four loads, so leaf tests cost no memory round trip of their own.
+//
+// gfx950 specifics: 64-wide ballots/popcounts for compaction, typed LDS/global address spaces (a pointer that may be either makes
+// hipcc emit flat_load), per-lane traversal stack in LDS as [entry][lane] (conflict-free ds_read/write_b64) with an HBM spill area
+// for unusually deep walks, LDS atomics for the per-slot completion words, no MFMA (there is no dense contraction on this path).
+#include "pt_device.h"
+#include "pt_kernels.h"
+#include "pt_shading.h"
+
+using namespace ptd;
+
+namespace {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+typedef const f4v __attribute__((address_space(3))) *lds_f4_cptr;
+typedef const f4v __attribute__((address_space(1))) *glb_f4_cptr;
+typedef u2v __attribute__((address_space(3))) *lds_u2_ptr;
+typedef u2v __attribute__((address_space(1))) *glb_u2_ptr;
+typedef unsigned int __attribute__((address_space(3))) *lds_u32_ptr;
+
+template<bool IN_LDS>
+struct RecPtr {
+    typedef glb_f4_cptr type;
+};
+template<>
+struct RecPtr<true> {
+    typedef lds_f4_cptr type;
+};
+
+PT_D float4 to_f4(f4v v) {
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// slab test of the device walk: bounding_box.cpp:38-73 with std::min/std::max replaced by v_min_f32/v_max_f32.
+// The two differ only for NaN operands (the reference asserts there are none, bounding_box.cpp:60-61) and in the sign of a
+// zero result, and every use of the returned distance is an ordered comparison, for which -0 and +0 are the same value.
+PT_D float slab_walk(V3 lo, V3 hi, V3 o, V3 inv) {
+    const float t1 = (lo.x - o.x) * inv.x;
+    const float t2 = (hi.x - o.x) * inv.x;
+    const float t3 = (lo.y - o.y) * inv.y;
+    const float t4 = (hi.y - o.y) * inv.y;
+    const float t5 = (lo.z - o.z) * inv.z;
+    const float t6 = (hi.z - o.z) * inv.z;
+    const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1, t2), __builtin_fminf(t3, t4)), __builtin_fminf(t5, t6));
+    const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1, t2), __builtin_fmaxf(t3, t4)), __builtin_fmaxf(t5, t6));
+    if(t_max < 0.0f || t_min > t_max) {
+        return -1.0f;
+    }
+    return t_min < 0.0f ? 0.0f : t_min; // origin inside: t_min < 0 <= t_max (bounding_box.cpp:68-70)
+}
+
+// One walk (one ray) in a lane.
+struct Walk {
+    V3 o, d, inv;
+    float thr;       // shadow threshold |to_light| - epsilon (worker.cpp:86)
+    uint32_t dest;   // destination word of the ray
+    float best_t;
+    uint32_t best_ref;
+    float t_max;
+    uint32_t cur;    // node or leaf the walk stands on; PT_REF_NONE = finished
+    uint32_t sp;
+    bool occluded;   // shadow ray: a leaf closer than the light was found
+};
+
+// The traversal machinery of one lane: record arrays (LDS or HBM), the stack window in LDS and its HBM spill area.
+template<int STACK_LDS, bool IN_LDS>
+struct Tracer {
+    typedef typename RecPtr<IN_LDS>::type rec_ptr;
+    rec_ptr pairs, tris;
+    const float4 *spheres;
+    lds_u2_ptr stack_l; // this thread's column: entry e at stack_l[e * 256]
+    glb_u2_ptr my_spill;
+
+    // The top STACK_LDS entries of a lane live in LDS (slot = index mod STACK_LDS), older ones in the lane's HBM spill area.
+    // Pushing onto a full window first moves the entry that is about to be overwritten to HBM; popping from a deep stack brings it
+    // back.  Walks rarely go deeper than the window, so the common path is one LDS access.
+    PT_D void push(uint32_t &sp, uint32_t ref, float entry_t) const {
+        const uint32_t slot = (sp % (uint32_t)STACK_LDS) * 256u;
+        if(sp >= (uint32_t)STACK_LDS) {
+            my_spill[sp - STACK_LDS] = stack_l[slot];
+        }
+        const u2v ev = {ref, __float_as_uint(entry_t)};
+        stack_l[slot] = ev;
+        sp++;
+    }
+    PT_D u2v pop(uint32_t &sp) const {
+        sp--;
+        const uint32_t slot = (sp % (uint32_t)STACK_LDS) * 256u;
+        const u2v e = stack_l[slot];
+        if(sp >= (uint32_t)STACK_LDS) {
+            stack_l[slot] = my_spill[sp - STACK_LDS];
+        }
+        return e;
+    }
+
+    // Start a walk: Scene::getIntersection tests the root box first (scene.cpp:211-219).
+    PT_D void start(Walk &w, const PtDevScene &sc, float4 ro, float4 rd) const {
+        w.o = v3(ro.x, ro.y, ro.z);
+        w.d = v3(rd.x, rd.y, rd.z);
+        w.thr = ro.w;
+        w.dest = __float_as_uint(rd.w);
+        w.inv = slab_inverse(w.d);
+        w.best_ref = PT_REF_NONE;
+        w.best_t = -1.0f;
+        // a shadow ray only asks for a hit nearer than the light: nothing that is entered at or beyond that distance can hold one,
+        // so the walk starts with the threshold as its pruning distance
+        w.t_max = (w.dest & PT_DEST_SHADOW) ? w.thr : FLT_MAX;
+        w.sp = 0;
+        w.occluded = false;
+        w.cur = PT_REF_NONE;
+        if(sc.root_ref != PT_REF_NONE) {
+            const float t_root = slab_walk(ld3(sc.root_lo), ld3(sc.root_hi), w.o, w.inv);
+            if(t_root >= 0.0f) {
+                w.cur = sc.root_ref;
+            }
+        }
+    }
+
+    // One step of a walk standing on a node or a leaf (w.cur != PT_REF_NONE).
+    PT_D void step(Walk &w, uint32_t &n_nodes, uint32_t &n_leaves) const {
+        const bool is_leaf = (w.cur & PT_REF_LEAF) != 0;
+        const uint32_t idx = w.cur & PT_REF_INDEX;
+        bool need_pop = false;
+        float t_leaf = -1.0f;
+        if(is_leaf && (w.cur & PT_REF_SPHERE)) {
+            const float4 s = spheres[idx];
+            t_leaf = sphere_intersect(v3(s.x, s.y, s.z), s.w, w.o, w.d);
+        }
+        else {
+            // the record the walk stands on: a node's pair of child boxes (64 bytes) or a triangle (48 bytes; the fourth load reads
+            // into the next record -- the arrays are padded -- and is ignored).  All four loads are issued before anything waits.
+            rec_ptr p = is_leaf ? tris + 3 * (size_t)idx : pairs + 4 * (size_t)idx;
+            f4v r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)); // keeps the fourth load next to the others (the compiler sinks it into the node branch)
+            const float4 q0 = to_f4(r0), q1 = to_f4(r1), q2 = to_f4(r2), q3 = to_f4(r3);
+            if(!is_leaf) {
+                n_nodes++;
+                // AABB::getIntersection of both children (bounding_box.cpp:38-73): a box is hit iff t_max >= 0 and t_min <= t_max, its
+                // entry distance is max(t_min, 0) (0 = origin inside, :68-70).  impl::getChildIntersection (scene.cpp:113-146): a
+                // child is entered iff it is hit and its entry distance is below the pruning distance (entry >= 0 holds for every hit);
+                // with both entered the nearer one comes first -- on equal distances the RIGHT one (scene.cpp:120-121).
+                const V3 o = w.o, inv = w.inv;
+                const float l1 = (q0.x - o.x) * inv.x, l2 = (q0.w - o.x) * inv.x;
+                const float l3 = (q0.y - o.y) * inv.y, l4 = (q1.x - o.y) * inv.y;
+                const float l5 = (q0.z - o.z) * inv.z, l6 = (q1.y - o.z) * inv.z;
+                const float r1t = (q1.z - o.x) * inv.x, r2t = (q2.y - o.x) * inv.x;
+                const float r3t = (q1.w - o.y) * inv.y, r4t = (q2.z - o.y) * inv.y;
+                const float r5t = (q2.x - o.z) * inv.z, r6t = (q2.w - o.z) * inv.z;
+                const float l_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(l1, l2), __builtin_fminf(l3, l4)), __builtin_fminf(l5, l6));
+                const float l_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(l1, l2), __builtin_fmaxf(l3, l4)), __builtin_fmaxf(l5, l6));
+                const float r_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r1t, r2t), __builtin_fminf(r3t, r4t)), __builtin_fminf(r5t, r6t));
+                const float r_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r1t, r2t), __builtin_fmaxf(r3t, r4t)), __builtin_fmaxf(r5t, r6t));
+                const float left_t = __builtin_fmaxf(l_min, 0.0f), right_t = __builtin_fmaxf(r_min, 0.0f);
+                const bool go_left = l_max >= 0.0f && l_min <= l_max && left_t < w.t_max;
+                const bool go_right = r_max >= 0.0f && r_min <= r_max && right_t < w.t_max;
+                const uint32_t left_ref = __float_as_uint(q3.x);
+                const uint32_t right_ref = __float_as_uint(q3.y);
+                const bool left_first = left_t < right_t;
+                if(go_left && go_right) {
+                    push(w.sp, left_first ? right_ref : left_ref, left_first ? right_t : left_t);
+                    w.cur = left_first ? left_ref : right_ref;
+                }
+                else {
+                    w.cur = go_left ? left_ref : right_ref;
+                }
+                need_pop = !go_left && !go_right;
+            }
+            else {
+                const TriRec tr = tri_unpack(q0, q1, q2);
+                t_leaf = tri_intersect(tr.a, tr.ab, tr.ac, (tr.obj_cull >> 31) != 0, w.o, w.d);
+            }
+        }
+        if(is_leaf) {
+            n_leaves++;
+            need_pop = true;
+            if(t_leaf >= 0.0f) {
+                if((w.dest & PT_DEST_SHADOW) && t_leaf < w.thr) {
+                    w.occluded = true; // worker.cpp:86: a hit closer than the light
+                    need_pop = false;
+                    w.cur = PT_REF_NONE;
+                }
+                else {
+                    if(w.best_ref == PT_REF_NONE || !(w.best_t < t_leaf)) {
+                        w.best_t = t_leaf;
+                        w.best_ref = w.cur;
+                    }
+                    w.t_max = fmin_std(w.t_max, t_leaf);
+                }
+            }
+        }
+        if(need_pop) {
+            // the first parked node whose entry distance is still below t_max
+            w.cur = PT_REF_NONE;
+            while(w.sp > 0) {
+                const u2v e = pop(w.sp);
+                if(__uint_as_float(e.y) < w.t_max) {
+                    w.cur = e.x;
+                    break;
+                }
+            }
+        }
+    }
+};
+
+// ---- the per-slot word in LDS ---------------------------------------------------------------------------------------------------------
+// bits 0..7   visibility of the last vertex's light samples (1 = unoccluded), set by the lanes that finish the shadow rays
+// bits 8..15  rays of the slot still in the queue or being walked
+// bits 16..   PT_F_* flags of the slot
+#define PT_W_PENDING(word) (((word) >> 8) & 0xffu)
+#define PT_W_FLAGS(word) ((word) >> 16)
+#define PT_W_ONE_RAY 0x100u
+
+#define PT_DEST_SLOT_MASK 0xffffu
+#define PT_DEST_J_SHIFT 16
+
+// What a wavefront keeps about itself (everything wave-uniform).
+struct WaveCtx {
+    uint32_t q_head;   // index of the oldest queued ray inside the wave's ring
+    uint32_t q_count;  // queued rays
+    uint32_t n_dead;   // slots that will never get a stream again
+    bool pool_empty;   // the global stream counter has run out
+};
+
+// Stream i of a tile job: pixel i of the tiles laid end to end (pt_render_tiles)
+PT_D void tile_stream(const PtStreams &T, uint32_t i, int4 &rect, uint64_t &rng, uint32_t &tile) {
+    uint32_t lo = 0, hi = T.n_tiles;
+    while(hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if(T.tile_offset[mid] <= i) {
+            lo = mid;
+        }
+        else {
+            hi = mid;
+        }
+    }
+    const int4 t = T.tiles[lo];
+    const uint32_t k = i - T.tile_offset[lo];
+    const int32_t x = t.x + (int32_t)(k % (uint32_t)t.z), y = t.y + (int32_t)(k / (uint32_t)t.z);
+    rect = make_int4(x, y, 1, 1);
+    const uint64_t seed = pixel_seed(T.base_seed, x, y);
+    rng = seed ^ (~seed << 32); // RandomEngine(seed), base.h:26
+    tile = lo;
+}
+
+// One shading pass over row `row` of the wave's slots: the state machine of one stream per lane.
+//   * a slot without a stream takes the next one from the global counter (or dies when there is none left);
+//   * a slot whose rays have all come back first adds the unoccluded light samples of its previous vertex to out_spectrum in the
+//     reference's order (worker.cpp:76-103), then looks at the extension ray's hit: miss -> the sample is finished (estimator, next
+//     sample or pixel); hit -> shade that vertex: emission (worker.cpp:62-64), Russian-roulette draw (:67-70), light sampling
+//     (Scene::sampleLights, scene.cpp:222-289) with one shadow ray per light sample, BSDF sample (:117-131).
+// A path that ends at a vertex (roulette) still has that vertex's shadow rays to wait for; where the estimator provably cannot stop
+// at this sample, the NEXT sample's camera ray is drawn and traced together with them (PT_F_OVERLAP) -- the draws keep their order.
+// The random draws of one stream are consumed strictly in the reference's order because a stream has at most one path in flight
+// and every draw of a vertex (roulette, lights, BSDF) is made by the single invocation that shades the vertex.
+// New rays go to the wave's ring: extension rays first, then the shadow rays light sample by light sample (ballot + prefix popcount
+// give every lane its position; rays of one kind from neighbouring pixels end up in neighbouring lanes of the traversal).
+PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOptions &opt, const PtSlots &S, const PtStreams &T, const PtLocalQueue &Q,
+                    WaveCtx &ctx, uint32_t row, uint32_t lane, size_t slot_base, size_t queue_base, lds_u32_ptr word_l, lds_u2_ptr hit_l,
+                    float4 *__restrict__ image, PtDevCounters *counters, uint32_t &n_samples, uint32_t &n_vertices) {
+    const uint32_t ls = row * 64 + lane; // slot of the wave
+    const size_t p = slot_base + ls;     // slot of the grid
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    const uint32_t n_light_samples = sc.n_lights + sc.n_object_samples;
+    const uint32_t word = word_l[ls];
+    uint32_t flags = PT_W_FLAGS(word);
+    const uint32_t vis_bits = word & 0xffu;
+    bool ready = !(flags & PT_F_DONE) && PT_W_PENDING(word) == 0;
+    if(__ballot(ready) == 0ULL) {
+        return;
+    }
+
+    // ---- slots without a stream: take the next one ------------------------------------------------------------------------------------
+    {
+        const bool want = ready && !(flags & PT_F_STREAM);
+        const unsigned long long want_mask = __ballot(want);
+        if(want_mask != 0ULL) {
+            uint32_t base = T.n;
+            if(!ctx.pool_empty) {
+                if(lane == 0) {
+                    base = atomicAdd(T.next, (uint32_t)__popcll(want_mask));
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
+            const uint32_t mine = base + (uint32_t)__popcll(want_mask & lt);
+            const bool got = want && base < T.n && mine < T.n;
+            if(base >= T.n || base + (uint32_t)__popcll(want_mask) > T.n) {
+                ctx.pool_empty = true;
+            }
+            if(got) {
+                int4 rc;
+                uint64_t r;
+                uint32_t tile = 0;
+                if(T.rect != nullptr) {
+                    rc = T.rect[mine];
+                    r = T.rng[mine];
+                }
+                else {
+                    tile_stream(T, mine, rc, r, tile);
+                }
+                S.stream[p] = mine;
+                S.rect[p] = rc;
+                S.rng[p] = r;
+                S.cursor[p] = 0;
+                flags = PT_F_STREAM;
+            }
+            else if(want) {
+                flags = PT_F_DONE;
+                ready = false;
+                word_l[ls] = PT_F_DONE << 16;
+            }
+            ctx.n_dead += (uint32_t)__popcll(__ballot(want && !got));
+        }
+    }
+    const bool alive = ready;
+
+    // ---- phase A: consume the results of the rays that came back -----------------------------------------------------------------------
+    uint64_t rng = 0;
+    C4 out = c4(0, 0, 0, 0), spectrum = c4(1, 1, 1, 1);
+    V3 ro = v3(0, 0, 0), rd = v3(0, 0, 1);
+    float contribution_unweighted = 1.0f;
+    double divisor = 1.0, bounce_pd = 1.0;
+    int path_length = 0;
+    bool shade_vertex = false; // the extension ray hit something
+    bool start_sample = false; // generate a camera ray
+    float hit_t = -1.0f;
+    uint32_t hit_ref = PT_REF_NONE;
+    int4 rect = make_int4(0, 0, 0, 0);
+    int32_t cursor = 0;
+    bool stream_finished = false;
+
+    if(alive) {
+        rng = S.rng[p];
+        rect = S.rect[p];
+        cursor = S.cursor[p];
+        if(flags & PT_F_IN_FLIGHT) {
+            out = c4(S.out[p]);
+            // shadow rays of the previous vertex, in light order (worker.cpp:76-103)
+            uint32_t mask = S.nee_mask[p];
+            for(uint32_t j = 0; mask != 0; j++, mask >>= 1) {
+                if((mask & 1u) && ((vis_bits >> j) & 1u)) {
+                    out = out + c4(S.nee[(size_t)j * S.total + p]);
+                }
+            }
+            if(flags & PT_F_OVERLAP) {
+                // the previous sample is complete now (worker.cpp:141-145, 196-237); it was collected (it had a vertex), it is
+                // not the pixel's last sample and the estimator cannot accept at it (see estimator_safe_to_overlap)
+                PtEstimator e = S.est[p];
+                out.a = 1.0f;
+                (void)estimator_add(e, S.cand + p * PT_MAX_CANDIDATES, opt, out);
+                e.pixel_sample++;
+                n_samples++;
+                S.est[p] = e;
+                flags &= ~(PT_F_OVERLAP | PT_F_COLLECTED | PT_F_SAFE);
+                if(estimator_safe_to_overlap(e, opt)) {
+                    flags |= PT_F_SAFE;
+                }
+                out = c4(0, 0, 0, 0);
+            }
+            bool finished = true;
+            if(flags & PT_F_HAS_EXT) {
+                const u2v h = hit_l[ls];
+                hit_t = __uint_as_float(h.x);
+                hit_ref = h.y;
+                if(!(hit_t < 0.0f)) {
+                    finished = false;
+                    shade_vertex = true;
+                }
+            }
+            if(finished) {
+                // getSample returns (worker.cpp:141-145); run the estimator
+                PtEstimator e = S.est[p];
+                PtCandidate *cand = S.cand + p * PT_MAX_CANDIDATES;
+                bool accepted = false;
+                if(flags & PT_F_COLLECTED) {
+                    out.a = 1.0f;
+                    accepted = estimator_add(e, cand, opt, out);
+                }
+                e.pixel_sample++;
+                n_samples++;
+                if(accepted || e.pixel_sample >= opt.max_sample_count) {
+                    // pixel finished (worker.cpp:263-319)
+                    const C4 value = estimator_finish(e, cand, opt, accepted);
+                    const int32_t px = rect.x + cursor % rect.z, py = rect.y + cursor / rect.z;
+                    image[(size_t)py * opt.image_width + px] = f4(value);
+                    cursor++;
+                    flags &= ~PT_F_PIXEL;
+                }
+                S.est[p] = e;
+                flags &= ~(PT_F_IN_FLIGHT | PT_F_HAS_EXT | PT_F_COLLECTED | PT_F_SAFE);
+                if((flags & PT_F_PIXEL) && estimator_safe_to_overlap(e, opt)) {
+                    flags |= PT_F_SAFE; // for the pixel's next sample, which starts below
+                }
+                start_sample = true;
+            }
+            else {
+                const float4 o4 = S.ray_o[p], d4 = S.ray_d[p];
+                ro = v3(o4.x, o4.y, o4.z);
+                rd = v3(d4.x, d4.y, d4.z);
+                contribution_unweighted = o4.w;
+                spectrum = c4(S.spectrum[p]);
+                divisor = S.divisor[p];
+                bounce_pd = S.bounce_pd[p];
+                path_length = S.path_length[p];
+            }
+        }
+        else {
+            start_sample = true;
+        }
+    }
+
+    // ---- start the next sample / pixel ------------------------------------------------------------------------------------
+    bool emit_ext = false;
+    Ray ext;
+    ext.o = v3(0, 0, 0);
+    ext.d = v3(0, 0, 1);
+    // camera ray through pixel `cur` of the stream's rectangle (worker.cpp:168-170, camera.cpp:78-113)
+    auto shoot_camera = [&](const int4 rc, int32_t cur) {
+        const int32_t px = rc.x + cur % rc.z, py = rc.y + cur / rc.z;
+        const float one_half = 1.0f / 2.0f;
+        const float x_camera = 2 * (((float)px + one_half) / (float)opt.image_width - one_half);
+        float y_camera = 2 * (((float)py + one_half) / (float)opt.image_height - one_half);
+        y_camera = -y_camera;
+        return camera_shoot(cam, x_camera, y_camera, opt.pixel_width, opt.pixel_height, rng);
+    };
+    if(start_sample) {
+        bool have_pixel = false;
+        while(cursor < rect.z * rect.w) {
+            if(!(flags & PT_F_PIXEL)) {
+                PtEstimator e;
+                estimator_reset(e, opt);
+                S.est[p] = e;
+                flags = (flags | PT_F_PIXEL) & ~PT_F_SAFE;
+                if(estimator_safe_to_overlap(e, opt)) {
+                    flags |= PT_F_SAFE;
+                }
+                if(opt.max_sample_count <= 0) {
+                    // no sample at all: the pixel stays (0, 0, 0, 0) (worker.cpp:193,263-265)
+                    const int32_t px = rect.x + cursor % rect.z, py = rect.y + cursor / rect.z;
+                    image[(size_t)py * opt.image_width + px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    cursor++;
+                    flags &= ~PT_F_PIXEL;
+                    continue;
+                }
+            }
+            have_pixel = true;
+            break;
+        }
+        if(!have_pixel) {
+            // the stream has rendered its whole rectangle: hand the engine back and free the slot (it takes a new stream in the next pass)
+            stream_finished = true;
+            flags = 0;
+        }
+        else {
+            ext = shoot_camera(rect, cursor);
+            emit_ext = true;
+            out = c4(0, 0, 0, 0);
+            spectrum = c4(1, 1, 1, 1);
+            contribution_unweighted = 1.0f;
+            divisor = 1.0;
+            bounce_pd = 1.0;
+            path_length = 0;
+            flags |= PT_F_IN_FLIGHT | PT_F_HAS_EXT;
+        }
+    }
+    {
+        const unsigned long long fin_mask = __ballot(stream_finished);
+        if(fin_mask != 0ULL) {
+            if(stream_finished) {
+                const uint32_t si = S.stream[p];
+                if(T.rng != nullptr) {
+                    T.rng[si] = rng;
+                }
+                if(T.tile_left != nullptr) {
+                    // progress: the last pixel of a tile reports the tile to the host (processJob's callback, worker.cpp:354-360)
+                    int4 rc_unused;
+                    uint64_t r_unused;
+                    uint32_t tile = 0;
+                    tile_stream(T, si, rc_unused, r_unused, tile);
+                    if(atomicSub(&T.tile_left[tile], 1u) == 1u) {
+                        __hip_atomic_fetch_add(T.tiles_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+            if(lane == 0) {
+                atomicAdd(&counters->streams_done, (unsigned long long)__popcll(fin_mask));
+            }
+        }
+    }
+
+    // ---- vertex, part 1: everything up to the Russian-roulette draw (worker.cpp:50-70) ---------------------------------------
+    V3 pos = v3(0, 0, 0), n = v3(0, 1, 0);
+    Material mat;
+    mat.bsdf = 0;
+    bool do_bounce = false;
+    float bounce_probability = 1.0f;
+    bool want_nee = false;
+    bool safe_overlap = false;
+    if(shade_vertex) {
+        path_length++;
+        flags |= PT_F_COLLECTED;
+        n_vertices++;
+        pos = ro + rd * hit_t;
+        uint32_t material_index;
+        n = object_normal(sc, hit_ref, pos, material_index);
+        mat = material_load(sc.materials, material_index);
+
+        out = out + (spectrum * mat.emission) / (float)(divisor * bounce_pd);
+
+        bounce_probability = path_length <= 4 ? 1.0f : 0.1f + 0.1f * fmin_std(contribution_unweighted * get_contribution(spectrum), 1.0f);
+        do_bounce = rng_uniform01(rng) < bounce_probability;
+        // BSDF::getSpectrum(..., synthetic = true) returns p = 0 for glass and mirror: their light samples never
+        // contribute (worker.cpp:92), so no shadow ray is needed -- the light-sampling draws are still consumed below.
+        want_nee = mat.bsdf == 0 && n_light_samples > 0;
+        safe_overlap = (flags & PT_F_SAFE) != 0; // decided when the sample started (estimator_safe_to_overlap)
+        // an extension ray: the bounce (may still be cancelled by the 1E-20 guards, worker.cpp:112,134) or the next sample's camera ray
+        emit_ext = do_bounce || safe_overlap;
+    }
+
+    // ---- positions in the wave's ring: extension rays first (the long walks start first) -------------------------------------------------
+    uint32_t tail = ctx.q_head + ctx.q_count; // may be >= cap: wrapped per entry below
+    const unsigned long long ext_mask = __ballot(emit_ext);
+    const uint32_t ext_pos = tail + (uint32_t)__popcll(ext_mask & lt);
+    tail += (uint32_t)__popcll(ext_mask);
+    ctx.q_count += (uint32_t)__popcll(ext_mask);
+    auto ring = [&](uint32_t i) -> size_t { return queue_base + (i >= Q.cap ? i - Q.cap : i); };
+
+    // ---- vertex, part 2: light sampling, shadow rays (worker.cpp:73-103) -------------------------------------------------------------------
+    uint32_t nee_out_mask = 0;
+    uint32_t vis_init = 0;
+    uint32_t n_rays = 0;
+    const float epsilon = opt.epsilon;
+    for(uint32_t j = 0; j < n_light_samples; j++) { // wave-uniform trip count
+        bool need_ray = false;
+        float4 so = make_float4(0, 0, 0, 0), sd = make_float4(0, 0, 0, 0);
+        if(shade_vertex) {
+            V3 light_pos;
+            C4 light_spectrum;
+            float lpd;
+            bool valid;
+            if(j < sc.n_lights) {
+                // PointLightSource: its position, its spectrum, pd = 1 (light.cpp:35-41)
+                const float4 lp = sc.lights[2 * j];
+                light_pos = v3(lp.x, lp.y, lp.z);
+                light_spectrum = c4(sc.lights[2 * j + 1]);
+                lpd = 1.0f;
+                valid = true;
+            }
+            else {
+                valid = sample_emissive(sc, pos, rng, light_pos, light_spectrum, lpd);
+            }
+            if(valid && want_nee) {
+                const V3 to_light = light_pos - pos;
+                const V3 light_dir = normalize(to_light);
+                float shading_factor, shadow_ray_pd;
+                const C4 base_spectrum = bsdf_spectrum(mat, rd, light_dir, n, light_spectrum, true, shading_factor, shadow_ray_pd);
+                if(shadow_ray_pd > 0.0f) {
+                    const C4 combined = (base_spectrum * shading_factor) * spectrum;
+                    const C4 weighed = combined / (float)(divisor * bounce_pd * lpd * shadow_ray_pd);
+                    // adding +-0 never changes out_spectrum (which is never -0), so such a sample needs no ray
+                    if(!(weighed.r == 0.0f && weighed.g == 0.0f && weighed.b == 0.0f)) {
+                        S.nee[(size_t)j * S.total + p] = f4(weighed);
+                        nee_out_mask |= 1u << j;
+                        const float threshold = len(to_light) - epsilon;
+                        if(threshold <= 0.0f) {
+                            // light_t < 0 || light_t >= threshold holds for every light_t
+                            vis_init |= 1u << j;
+                        }
+                        else {
+                            need_ray = true;
+                            const V3 o2 = pos + light_dir * epsilon;
+                            so = make_float4(o2.x, o2.y, o2.z, threshold);
+                            sd = make_float4(light_dir.x, light_dir.y, light_dir.z, __uint_as_float(PT_DEST_SHADOW | (j << PT_DEST_J_SHIFT) | ls));
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long ray_mask = __ballot(need_ray);
+        if(ray_mask != 0ULL) {
+            if(need_ray) {
+                const size_t at = ring(tail + (uint32_t)__popcll(ray_mask & lt));
+                Q.ray_o[at] = so;
+                Q.ray_d[at] = sd;
+                n_rays++;
+            }
+            tail += (uint32_t)__popcll(ray_mask);
+            ctx.q_count += (uint32_t)__popcll(ray_mask);
+        }
+    }
+
+    // ---- vertex, part 3: the bounce (worker.cpp:105-138) ---------------------------------------------------------------------------------
+    if(shade_vertex) {
+        bool cancel_ext = false;
+        if(!do_bounce) {
+            // worker.cpp:106-109: the path ends here
+        }
+        else {
+            bounce_pd *= bounce_probability;
+            if(bounce_pd <= 1E-20) {
+                cancel_ext = true;
+            }
+            else {
+                float ray_factor, ray_pd;
+                const Ray next_ray = bsdf_propagate(mat, rd, pos, n, epsilon, rng, ray_factor, ray_pd);
+                divisor *= ray_pd;
+                divisor /= ray_factor;
+                contribution_unweighted *= ray_factor;
+                float shading_factor, shading_pd;
+                const C4 shaded = bsdf_spectrum(mat, rd, next_ray.d, n, spectrum, false, shading_factor, shading_pd);
+                divisor *= shading_pd;
+                divisor /= shading_factor;
+                contribution_unweighted *= shading_factor;
+                spectrum = shaded;
+                if(divisor <= 1E-20) {
+                    cancel_ext = true;
+                }
+                else {
+                    ext = next_ray;
+                }
+            }
+        }
+        const bool path_ends = !do_bounce || cancel_ext;
+        if(path_ends && safe_overlap) {
+            // start the next sample of this pixel now; this sample is finished by the next pass over the slot (PT_F_OVERLAP)
+            ext = shoot_camera(rect, cursor);
+            spectrum = c4(1, 1, 1, 1);
+            contribution_unweighted = 1.0f;
+            divisor = 1.0;
+            bounce_pd = 1.0;
+            path_length = 0;
+            flags |= PT_F_OVERLAP;
+        }
+        else if(path_ends && emit_ext) {
+            // the reserved position stays a hole (a bounce cancelled by the 1E-20 guards: rare)
+            Q.ray_d[ring(ext_pos)] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PT_DEST_NULL));
+            emit_ext = false;
+        }
+        if(emit_ext) {
+            flags |= PT_F_HAS_EXT;
+        }
+        else {
+            flags &= ~PT_F_HAS_EXT;
+        }
+    }
+
+    // ---- write the extension ray and the path state ------------------------------------------------------------------------------
+    if(emit_ext) {
+        const size_t at = ring(ext_pos);
+        Q.ray_o[at] = make_float4(ext.o.x, ext.o.y, ext.o.z, 0.0f);
+        Q.ray_d[at] = make_float4(ext.d.x, ext.d.y, ext.d.z, __uint_as_float(ls));
+        n_rays++;
+    }
+    if(alive) {
+        word_l[ls] = (flags << 16) | (n_rays << 8) | vis_init;
+        S.rng[p] = rng;
+        S.cursor[p] = cursor;
+        if(flags & PT_F_IN_FLIGHT) {
+            S.ray_o[p] = make_float4(ext.o.x, ext.o.y, ext.o.z, contribution_unweighted);
+            S.ray_d[p] = make_float4(ext.d.x, ext.d.y, ext.d.z, 0.0f);
+            S.spectrum[p] = f4(spectrum);
+            S.out[p] = f4(out);
+            S.divisor[p] = divisor;
+            S.bounce_pd[p] = bounce_pd;
+            S.path_length[p] = path_length;
+            S.nee_mask[p] = nee_out_mask;
+        }
+    }
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------------------------------------
+
+#ifndef PT_PATH_WAVES
+#define PT_PATH_WAVES 3
+#endif
+
+template<int STACK_LDS, bool IN_LDS>
+__global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene sc, PtDevCamera cam, PtDevOptions opt, PtSlots S, PtStreams T, PtLocalQueue Q, int rows,
+                                                                    int refill_idle, int min_ready, int burst_steps, int leaf_min, uint2 *__restrict__ spill,
+                                                                    uint32_t spill_depth, float4 *__restrict__ image, PtDevCounters *counters,
+                                                                    unsigned long long *__restrict__ wave_counters) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    // LDS of the workgroup: traversal stacks [STACK_LDS][256] | hit records [4 waves][rows * 64] | slot words [4 waves][rows * 64] |
+    // (small scenes) the whole tree and all triangle records
+    const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)tid & 63u;
+    const uint32_t wave_in_block = (uint32_t)tid >> 6;
+    const uint32_t wave = blockIdx.x * 4u + wave_in_block;
+    const uint32_t n_slots = (uint32_t)rows * 64u;
+    unsigned char *at = lds_raw;
+    lds_u2_ptr stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(at) + tid;
+    at += (size_t)STACK_LDS * 256 * sizeof(uint2);
+    lds_u2_ptr hit_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(at) + wave_in_block * n_slots;
+    at += (size_t)4 * n_slots * sizeof(uint2);
+    lds_u32_ptr word_l = (lds_u32_ptr)reinterpret_cast<uint32_t *>(at) + wave_in_block * n_slots;
+    at += (size_t)4 * n_slots * sizeof(uint32_t);
+    float4 *lds_pairs = reinterpret_cast<float4 *>(at);
+    float4 *lds_tris = lds_pairs + 4 * (size_t)sc.n_lds_pairs;
+
+    if(IN_LDS) {
+        for(uint32_t i = tid; i < 4 * sc.n_lds_pairs; i += 256) {
+            lds_pairs[i] = sc.pairs[i];
+        }
+        for(uint32_t i = tid; i < 3 * sc.n_lds_tris + 1; i += 256) { // + 1: the padding word the fourth load of the last triangle reads
+            lds_tris[i] = i < 3 * sc.n_lds_tris ? sc.tris[i] : make_float4(0, 0, 0, 0);
+        }
+    }
+    for(uint32_t i = lane; i < n_slots; i += 64) {
+        word_l[i] = 0; // no stream, nothing pending: ready to take a stream
+    }
+    __syncthreads(); // the only barrier: from here on the four wavefronts of the workgroup never wait for each other
+
+    Tracer<STACK_LDS, IN_LDS> tr;
+    if(IN_LDS) {
+        tr.pairs = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_pairs;
+        tr.tris = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_tris;
+    }
+    else {
+        tr.pairs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.pairs;
+        tr.tris = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.tris;
+    }
+    tr.spheres = sc.spheres;
+    tr.stack_l = stack_l;
+    tr.my_spill = (glb_u2_ptr)(spill + ((size_t)wave * 64 + lane) * spill_depth);
+
+    const size_t slot_base = (size_t)wave * n_slots;
+    const size_t queue_base = (size_t)wave * Q.cap;
+    WaveCtx ctx;
+    ctx.q_head = 0;
+    ctx.q_count = 0;
+    ctx.n_dead = 0;
+    ctx.pool_empty = false;
+
+    bool active = false;
+    Walk w;
+    w.o = v3(0, 0, 0);
+    w.d = v3(0, 0, 1);
+    w.inv = v3(0, 0, 0);
+    w.thr = 0.0f;
+    w.dest = 0;
+    w.best_t = 0.0f;
+    w.best_ref = PT_REF_NONE;
+    w.t_max = FLT_MAX;
+    w.cur = PT_REF_NONE;
+    w.sp = 0;
+    w.occluded = false;
+    uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0, n_samples = 0, n_vertices = 0;
+    uint32_t w_steps = 0, w_passes = 0; // wave-level diagnostics (same value in every lane)
+#ifdef PT_PATH_TIMING
+    unsigned long long t_shade = 0, t_burst = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+
+    for(;;) {
+        // ---- 1. retire finished walks: the result goes to the slot's words in LDS ---------------------------------------------------------
+        if(active && w.cur == PT_REF_NONE) {
+            const uint32_t ls = w.dest & PT_DEST_SLOT_MASK;
+            if(w.dest & PT_DEST_SHADOW) {
+                const uint32_t j = (w.dest >> PT_DEST_J_SHIFT) & 7u;
+                // one ray less pending; an unoccluded light sample sets its visibility bit
+                __hip_atomic_fetch_add(&word_l[ls], (w.occluded ? 0u : (1u << j)) - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            else {
+                const u2v h = {__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref};
+                hit_l[ls] = h;
+                __hip_atomic_fetch_add(&word_l[ls], 0u - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            active = false;
+        }
+
+        // ---- 2. idle lanes: hand out queued rays; with the queue empty, shade what has come back ----------------------------------------
+        const unsigned long long idle_mask = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if(n_idle >= (uint32_t)refill_idle) {
+            if(ctx.q_count == 0 && ctx.n_dead < n_slots) {
+                // slots whose rays have all come back (or that wait for a stream)
+                uint32_t n_ready = 0;
+                for(uint32_t r = 0; r < (uint32_t)rows; r++) {
+                    const uint32_t word = word_l[r * 64 + lane];
+                    n_ready += (uint32_t)__popcll(__ballot(!(PT_W_FLAGS(word) & PT_F_DONE) && PT_W_PENDING(word) == 0));
+                }
+                if(n_ready >= (uint32_t)min_ready || n_idle == 64u) {
+                    w_passes++;
+#ifdef PT_PATH_TIMING
+                    const unsigned long long t_pass = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+                    for(uint32_t r = 0; r < (uint32_t)rows; r++) {
+                        shade_row(sc, cam, opt, S, T, Q, ctx, r, lane, slot_base, queue_base, word_l, hit_l, image, counters, n_samples, n_vertices);
+                    }
+                    // the rays just written are read back by other lanes of this wavefront
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_s_waitcnt(0);
+#ifdef PT_PATH_TIMING
+                    t_shade += __builtin_amdgcn_s_memtime() - t_pass;
+#endif
+                }
+            }
+            if(ctx.q_count > 0) {
+                const uint32_t take = ctx.q_count < n_idle ? ctx.q_count : n_idle;
+                if(!active) {
+                    const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
+                    if(rank < take) {
+                        uint32_t i = ctx.q_head + rank;
+                        i = i >= Q.cap ? i - Q.cap : i;
+                        const float4 ro = Q.ray_o[queue_base + i];
+                        const float4 rd = Q.ray_d[queue_base + i];
+                        if(__float_as_uint(rd.w) != PT_DEST_NULL) {
+                            tr.start(w, sc, ro, rd);
+                            active = true;
+                            n_rays++;
+                            n_shadow += (w.dest & PT_DEST_SHADOW) ? 1u : 0u;
+                        }
+                    }
+                }
+                ctx.q_head += take;
+                ctx.q_head = ctx.q_head >= Q.cap ? ctx.q_head - Q.cap : ctx.q_head;
+                ctx.q_count -= take;
+            }
+        }
+        if(__ballot(active) == 0ULL) {
+            if(ctx.q_count == 0 && ctx.n_dead >= n_slots) {
+                break; // every slot is dead, nothing queued, nothing walking
+            }
+            continue;
+        }
+
+        // ---- 3. a burst of traversal steps -------------------------------------------------------------------------------------------------
+        // Lanes that stand on a leaf wait (their order of visits is unchanged) until `leaf_min` of them can share the leaf code, or no
+        // lane has an inner node left; the leaf test then rides along with the other lanes' node step (one memory round trip for both).
+#ifdef PT_PATH_TIMING
+        const unsigned long long t_b0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+        for(int burst = 0; burst < burst_steps; burst++) {
+            const bool standing = active && w.cur != PT_REF_NONE;
+            const bool at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
+            const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
+            if((leaf_mask | node_mask) == 0ULL) {
+                break;
+            }
+            const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
+            w_steps++;
+            if(standing && (!at_leaf || do_leaves)) {
+                tr.step(w, n_nodes, n_leaves);
+            }
+        }
+#ifdef PT_PATH_TIMING
+        t_burst += __builtin_amdgcn_s_memtime() - t_b0;
+#endif
+    }
+
+    // Work counters: every wave owns one 64-byte slot (plain stores; atomics on a shared line from every wave serialise at the memory side)
+    for(int off = 32; off > 0; off >>= 1) {
+        n_nodes += __shfl_down(n_nodes, off);
+        n_leaves += __shfl_down(n_leaves, off);
+        n_rays += __shfl_down(n_rays, off);
+        n_shadow += __shfl_down(n_shadow, off);
+        n_samples += __shfl_down(n_samples, off);
+        n_vertices += __shfl_down(n_vertices, off);
+    }
+    if(lane == 0) {
+        unsigned long long *slot = wave_counters + 8 * (size_t)wave;
+        slot[0] += n_nodes;
+        slot[1] += n_leaves;
+        slot[2] += n_rays;
+        slot[3] += n_shadow;
+        slot[4] += w_steps;
+        slot[5] += w_passes;
+        slot[6] += n_samples;
+        slot[7] += n_vertices;
+#ifdef PT_PATH_TIMING
+        // diagnostic build: shader-clock cycles of this wavefront in shading passes, in traversal bursts, and in all
+        slot[5] = (unsigned long long)w_passes | ((t_shade >> 10) << 32);
+        slot[4] = (unsigned long long)w_steps | ((t_burst >> 10) << 32);
+        slot[3] = (unsigned long long)n_shadow | (((__builtin_amdgcn_s_memtime() - t_begin) >> 10) << 32);
+#endif
+    }
+}
+
+// Scene::getIntersection for a batch of rays: one walk per lane, the same traversal machinery
+template<int STACK_LDS, bool IN_LDS>
+__global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const float *__restrict__ rays6, uint32_t n, uint2 *__restrict__ out, uint2 *__restrict__ spill,
+                                                         uint32_t spill_depth) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int tid = threadIdx.x;
+    lds_u2_ptr stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(lds_raw) + tid;
+    float4 *lds_pairs = reinterpret_cast<float4 *>(lds_raw + (size_t)STACK_LDS * 256 * sizeof(uint2));
+    float4 *lds_tris = lds_pairs + 4 * (size_t)sc.n_lds_pairs;
+    if(IN_LDS) {
+        for(uint32_t i = tid; i < 4 * sc.n_lds_pairs; i += 256) {
+            lds_pairs[i] = sc.pairs[i];
+        }
+        for(uint32_t i = tid; i < 3 * sc.n_lds_tris + 1; i += 256) {
+            lds_tris[i] = i < 3 * sc.n_lds_tris ? sc.tris[i] : make_float4(0, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    Tracer<STACK_LDS, IN_LDS> tr;
+    if(IN_LDS) {
+        tr.pairs = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_pairs;
+        tr.tris = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_tris;
+    }
+    else {
+        tr.pairs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.pairs;
+        tr.tris = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.tris;
+    }
+    tr.spheres = sc.spheres;
+    tr.stack_l = stack_l;
+    const size_t gid = (size_t)blockIdx.x * 256 + tid;
+    tr.my_spill = (glb_u2_ptr)(spill + gid * spill_depth);
+    if(gid >= n) {
+        return;
+    }
+    const float *r = rays6 + 6 * gid;
+    Walk w;
+    tr.start(w, sc, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
+    uint32_t n_nodes = 0, n_leaves = 0;
+    while(w.cur != PT_REF_NONE) {
+        tr.step(w, n_nodes, n_leaves);
+    }
+    out[gid] = make_uint2(__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref);
+}
+
+template<int STACK_LDS, bool IN_LDS>
+void launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams, PtLocalQueue queue,
+                 const PtPathConfig &cfg, float4 *image, PtDevCounters *counters) {
+    hipLaunchKernelGGL((pt_path_kernel<STACK_LDS, IN_LDS>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, camera, options, slots, streams, queue, cfg.rows,
+                       cfg.refill_idle, cfg.min_ready, cfg.burst_steps, cfg.leaf_min, cfg.spill, cfg.spill_depth, image, counters, cfg.wave_counters);
+}
+
+template<int STACK_LDS, bool IN_LDS>
+int occupancy(size_t lds_bytes) {
+    int blocks = 0;
+    const hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_path_kernel<STACK_LDS, IN_LDS>, 256, lds_bytes);
+    return (err != hipSuccess || blocks < 1) ? 1 : blocks;
+}
+
+template<int STACK_LDS, bool IN_LDS>
+void launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg) {
+    const size_t lds = (size_t)STACK_LDS * 256 * sizeof(uint2) + (IN_LDS ? (size_t)scene.n_lds_pairs * 64 + (size_t)scene.n_lds_tris * 48 + 16 : 0);
+    hipLaunchKernelGGL((pt_closest_kernel<STACK_LDS, IN_LDS>), dim3((n + 255) / 256), dim3(256), lds, stream, scene, rays6, n, out, cfg.spill, cfg.spill_depth);
+}
+
+} // namespace
+
+#define PT_DISPATCH(fn, cfg, ...)                                  \
+    do {                                                           \
+        if((cfg).in_lds) {                                         \
+            if((cfg).stack_lds == 8) {                             \
+                fn<8, true>(__VA_ARGS__);                          \
+            }                                                      \
+            else {                                                 \
+                fn<16, true>(__VA_ARGS__);                         \
+            }                                                      \
+        }                                                          \
+        else {                                                     \
+            if((cfg).stack_lds == 8) {                             \
+                fn<8, false>(__VA_ARGS__);                         \
+            }                                                      \
+            else {                                                 \
+                fn<16, false>(__VA_ARGS__);                        \
+            }                                                      \
+        }                                                          \
+    } while(0)
+
+void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams,
+                    PtLocalQueue queue, const PtPathConfig &cfg, float4 *image, PtDevCounters *counters) {
+    PT_DISPATCH(launch_path, cfg, stream, scene, camera, options, slots, streams, queue, cfg, image, counters);
+}
+
+void pt_launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg) {
+    if(n == 0) {
+        return;
+    }
+    PT_DISPATCH(launch_closest, cfg, stream, scene, rays6, n, out, cfg);
+}
+
+size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_tris) {
+    const size_t scene = (n_lds_pairs != 0 || n_lds_tris != 0) ? (size_t)n_lds_pairs * 64 + (size_t)n_lds_tris * 48 + 16 : 0;
+    return (size_t)stack_lds * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + sizeof(uint32_t)) + scene;
+}
+
+int pt_path_blocks_per_cu(int stack_lds, int in_lds, size_t lds_bytes) {
+    if(in_lds) {
+        return stack_lds == 8 ? occupancy<8, true>(lds_bytes) : occupancy<16, true>(lds_bytes);
+    }
+    return stack_lds == 8 ? occupancy<8, false>(lds_bytes) : occupancy<16, false>(lds_bytes);
+}

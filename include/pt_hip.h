@@ -154,6 +154,13 @@ int pt_render_streams(pt_scene *scene, const pt_camera_params *camera, const pt_
 int pt_render_tiles(pt_scene *scene, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles,
                     uint64_t base_seed, float *out_image, pt_stats *stats);
 
+/* Same, reporting progress the way processJob's progress_callback does (worker.h:75-84, src/worker.cpp:354-360): `progress(completed,
+ * total, user)` is called from the CALLING thread, never concurrently, with completed = 1 .. n_tiles in increasing order, while the
+ * device is still rendering (the kernel counts finished tiles in host-visible memory; the host polls).  NULL = no reporting. */
+typedef void (*pt_progress_fn)(int completed, int total, void *user);
+int pt_render_tiles_progress(pt_scene *scene, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles,
+                             uint64_t base_seed, float *out_image, pt_stats *stats, pt_progress_fn progress, void *user);
+
 /* Same, writing into DEVICE memory (e.g. a torch tensor's data_ptr) and ordered on `stream` (a hipStream_t, NULL = the
  * library's own stream followed by a synchronisation).  Used for the multi-GPU gather over RCCL. */
 int pt_render_tiles_device(pt_scene *scene, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles,

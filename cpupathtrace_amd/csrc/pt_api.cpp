@@ -209,6 +209,7 @@ struct pt_scene {
     DevBuf<PtEstimator> sl_est;
     DevBuf<PtCandidate> sl_cand;
     DevBuf<uint2> path_spill, closest_out;
+    DevBuf<uint32_t> walk_save;
     DevBuf<unsigned long long> path_wave_counters;
     uint32_t *host_tiles_done = nullptr; // pinned: tiles finished so far, written by the kernel (progress callback)
 
@@ -825,8 +826,8 @@ int setup_path(pt_scene *s) {
         return PT_OK;
     }
     cfg.in_lds = (s->dev.n_lds_pairs == s->dev.n_pairs && s->dev.n_lds_tris == s->dev.n_tris && s->dev.n_lds_pairs + s->dev.n_lds_tris > 0) ? 1 : 0;
-    // walks of a tree of at most 8 levels never leave an 8-entry window
-    int stack_lds = env_int("PT_STACK_LDS", s->depth <= 8 ? 8 : 16);
+    // 8 stack entries per lane in LDS (16 KB per workgroup) let four workgroups share a CU; deeper walks use the HBM spill area
+    int stack_lds = env_int("PT_STACK_LDS", 8);
     cfg.stack_lds = stack_lds == 8 ? 8 : 16;
     cfg.rows = std::min(std::max(env_int("PT_ROWS", 4), 1), PT_MAX_ROWS);
     cfg.lds_bytes = pt_path_lds_bytes(cfg.stack_lds, cfg.rows, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.n_lds_tris : 0U);
@@ -836,7 +837,7 @@ int setup_path(pt_scene *s) {
     cfg.spill_depth = s->depth > static_cast<uint32_t>(cfg.stack_lds) ? s->depth - static_cast<uint32_t>(cfg.stack_lds) : 1U;
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 12), 1), 64);
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
-    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 4), 1), 64);
+    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 8), 1), 64);
     cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 8), 1), 64);
     if(env_int("PT_DEBUG", 0) != 0) {
         std::fprintf(stderr, "[pt] path kernel: %d CUs x %d workgroups, %d rows of slots per wavefront, stack_lds %d, scene %s, lds %zu B, spill depth %u\n", s->cu_count,
@@ -880,9 +881,11 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     PT_HIP(s->lq_ray_d.ensure(static_cast<size_t>(waves) * cap));
     PT_HIP(s->path_spill.ensure(static_cast<size_t>(waves) * 64U * cfg.spill_depth));
     PT_HIP(s->path_wave_counters.ensure(static_cast<size_t>(waves) * 8U));
+    PT_HIP(s->walk_save.ensure(static_cast<size_t>(waves) * 64U * PT_WALK_SAVE_WORDS));
     PT_HIP(s->pull_counter.ensure(64));
     PT_HIP(s->counters.ensure(PT_MAX_GROUPS));
     cfg.spill = s->path_spill.ptr;
+    cfg.walk_save = s->walk_save.ptr;
     cfg.wave_counters = s->path_wave_counters.ptr;
     s->path_slots = total;
     s->path_waves = waves;

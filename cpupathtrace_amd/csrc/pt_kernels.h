@@ -107,6 +107,7 @@ int pt_trace_blocks_per_cu(int stack_lds, int lds_mode, size_t lds_bytes);
 // and tracing the rays that produced -- without ever synchronising with another wavefront.  A slot that has finished its stream pulls
 // the next one from a global counter.
 
+#define PT_WALK_SAVE_WORDS 17
 #define PT_MAX_ROWS 8      /* rows of 64 slots per wavefront */
 #define PT_F_STREAM 128u   /* the slot holds a stream (flag bit, next to PT_F_*) */
 
@@ -160,6 +161,7 @@ struct PtPathConfig {
     int stack_lds;        // traversal stack entries per lane kept in LDS
     uint32_t spill_depth; // further entries per lane in HBM
     uint2 *spill;
+    uint32_t *walk_save;  // [PT_WALK_SAVE_WORDS][grid * 256]: where a lane parks its walk during a shading pass
     size_t lds_bytes;
     int in_lds;           // whole tree + triangle records staged in LDS (small scenes)
     int refill_idle;      // idle lanes that make a wavefront refill from its queue (or shade when the queue is empty)

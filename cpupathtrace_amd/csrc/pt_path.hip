@@ -128,8 +128,28 @@ struct Tracer {
         return e;
     }
 
+    // The 64-byte record a walk stands on, fetched as soon as the walk knows where it goes next: a node's pair of child boxes, a
+    // triangle (48 bytes; the fourth load reads into the next record -- the arrays are padded -- and is ignored) or a sphere (first word).
+    struct Rec {
+        f4v r0, r1, r2, r3;
+    };
+    PT_D void fetch(const Walk &w, Rec &R) const {
+        const uint32_t idx = w.cur & PT_REF_INDEX;
+        if((w.cur & (PT_REF_LEAF | PT_REF_SPHERE)) == (PT_REF_LEAF | PT_REF_SPHERE)) {
+            const float4 s = spheres[idx];
+            R.r0 = (f4v){s.x, s.y, s.z, s.w};
+        }
+        else {
+            rec_ptr p = (w.cur & PT_REF_LEAF) ? tris + 3 * (size_t)idx : pairs + 4 * (size_t)idx;
+            R.r0 = p[0];
+            R.r1 = p[1];
+            R.r2 = p[2];
+            R.r3 = p[3];
+        }
+    }
+
     // Start a walk: Scene::getIntersection tests the root box first (scene.cpp:211-219).
-    PT_D void start(Walk &w, const PtDevScene &sc, float4 ro, float4 rd) const {
+    PT_D void start(Walk &w, Rec &R, const PtDevScene &sc, float4 ro, float4 rd) const {
         w.o = v3(ro.x, ro.y, ro.z);
         w.d = v3(rd.x, rd.y, rd.z);
         w.thr = ro.w;
@@ -147,66 +167,59 @@ struct Tracer {
             const float t_root = slab_walk(ld3(sc.root_lo), ld3(sc.root_hi), w.o, w.inv);
             if(t_root >= 0.0f) {
                 w.cur = sc.root_ref;
+                fetch(w, R);
             }
         }
     }
 
-    // One step of a walk standing on a node or a leaf (w.cur != PT_REF_NONE).
-    PT_D void step(Walk &w, uint32_t &n_nodes, uint32_t &n_leaves) const {
+    // One step of a walk standing on a node or a leaf (w.cur != PT_REF_NONE) whose record R was fetched when the walk got there;
+    // fetches the record of where the walk goes next.
+    PT_D void step(Walk &w, Rec &R, uint32_t &n_nodes, uint32_t &n_leaves) const {
         const bool is_leaf = (w.cur & PT_REF_LEAF) != 0;
-        const uint32_t idx = w.cur & PT_REF_INDEX;
         bool need_pop = false;
-        float t_leaf = -1.0f;
-        if(is_leaf && (w.cur & PT_REF_SPHERE)) {
-            const float4 s = spheres[idx];
-            t_leaf = sphere_intersect(v3(s.x, s.y, s.z), s.w, w.o, w.d);
+        const float4 q0 = to_f4(R.r0), q1 = to_f4(R.r1), q2 = to_f4(R.r2), q3 = to_f4(R.r3);
+        if(!is_leaf) {
+            n_nodes++;
+            // AABB::getIntersection of both children (bounding_box.cpp:38-73): a box is hit iff t_max >= 0 and t_min <= t_max, its
+            // entry distance is max(t_min, 0) (0 = origin inside, :68-70).  impl::getChildIntersection (scene.cpp:113-146): a
+            // child is entered iff it is hit and its entry distance is below the pruning distance (entry >= 0 holds for every hit);
+            // with both entered the nearer one comes first -- on equal distances the RIGHT one (scene.cpp:120-121).
+            const V3 o = w.o, inv = w.inv;
+            const float l1 = (q0.x - o.x) * inv.x, l2 = (q0.w - o.x) * inv.x;
+            const float l3 = (q0.y - o.y) * inv.y, l4 = (q1.x - o.y) * inv.y;
+            const float l5 = (q0.z - o.z) * inv.z, l6 = (q1.y - o.z) * inv.z;
+            const float r1t = (q1.z - o.x) * inv.x, r2t = (q2.y - o.x) * inv.x;
+            const float r3t = (q1.w - o.y) * inv.y, r4t = (q2.z - o.y) * inv.y;
+            const float r5t = (q2.x - o.z) * inv.z, r6t = (q2.w - o.z) * inv.z;
+            const float l_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(l1, l2), __builtin_fminf(l3, l4)), __builtin_fminf(l5, l6));
+            const float l_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(l1, l2), __builtin_fmaxf(l3, l4)), __builtin_fmaxf(l5, l6));
+            const float r_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r1t, r2t), __builtin_fminf(r3t, r4t)), __builtin_fminf(r5t, r6t));
+            const float r_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r1t, r2t), __builtin_fmaxf(r3t, r4t)), __builtin_fmaxf(r5t, r6t));
+            const float left_t = __builtin_fmaxf(l_min, 0.0f), right_t = __builtin_fmaxf(r_min, 0.0f);
+            const bool go_left = l_max >= 0.0f && l_min <= l_max && left_t < w.t_max;
+            const bool go_right = r_max >= 0.0f && r_min <= r_max && right_t < w.t_max;
+            const uint32_t left_ref = __float_as_uint(q3.x);
+            const uint32_t right_ref = __float_as_uint(q3.y);
+            const bool left_first = left_t < right_t;
+            if(go_left && go_right) {
+                push(w.sp, left_first ? right_ref : left_ref, left_first ? right_t : left_t);
+                w.cur = left_first ? left_ref : right_ref;
+            }
+            else {
+                w.cur = go_left ? left_ref : right_ref;
+            }
+            need_pop = !go_left && !go_right;
         }
         else {
-            // the record the walk stands on: a node's pair of child boxes (64 bytes) or a triangle (48 bytes; the fourth load reads
-            // into the next record -- the arrays are padded -- and is ignored).  All four loads are issued before anything waits.
-            rec_ptr p = is_leaf ? tris + 3 * (size_t)idx : pairs + 4 * (size_t)idx;
-            f4v r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
-            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)); // keeps the fourth load next to the others (the compiler sinks it into the node branch)
-            const float4 q0 = to_f4(r0), q1 = to_f4(r1), q2 = to_f4(r2), q3 = to_f4(r3);
-            if(!is_leaf) {
-                n_nodes++;
-                // AABB::getIntersection of both children (bounding_box.cpp:38-73): a box is hit iff t_max >= 0 and t_min <= t_max, its
-                // entry distance is max(t_min, 0) (0 = origin inside, :68-70).  impl::getChildIntersection (scene.cpp:113-146): a
-                // child is entered iff it is hit and its entry distance is below the pruning distance (entry >= 0 holds for every hit);
-                // with both entered the nearer one comes first -- on equal distances the RIGHT one (scene.cpp:120-121).
-                const V3 o = w.o, inv = w.inv;
-                const float l1 = (q0.x - o.x) * inv.x, l2 = (q0.w - o.x) * inv.x;
-                const float l3 = (q0.y - o.y) * inv.y, l4 = (q1.x - o.y) * inv.y;
-                const float l5 = (q0.z - o.z) * inv.z, l6 = (q1.y - o.z) * inv.z;
-                const float r1t = (q1.z - o.x) * inv.x, r2t = (q2.y - o.x) * inv.x;
-                const float r3t = (q1.w - o.y) * inv.y, r4t = (q2.z - o.y) * inv.y;
-                const float r5t = (q2.x - o.z) * inv.z, r6t = (q2.w - o.z) * inv.z;
-                const float l_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(l1, l2), __builtin_fminf(l3, l4)), __builtin_fminf(l5, l6));
-                const float l_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(l1, l2), __builtin_fmaxf(l3, l4)), __builtin_fmaxf(l5, l6));
-                const float r_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r1t, r2t), __builtin_fminf(r3t, r4t)), __builtin_fminf(r5t, r6t));
-                const float r_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r1t, r2t), __builtin_fmaxf(r3t, r4t)), __builtin_fmaxf(r5t, r6t));
-                const float left_t = __builtin_fmaxf(l_min, 0.0f), right_t = __builtin_fmaxf(r_min, 0.0f);
-                const bool go_left = l_max >= 0.0f && l_min <= l_max && left_t < w.t_max;
-                const bool go_right = r_max >= 0.0f && r_min <= r_max && right_t < w.t_max;
-                const uint32_t left_ref = __float_as_uint(q3.x);
-                const uint32_t right_ref = __float_as_uint(q3.y);
-                const bool left_first = left_t < right_t;
-                if(go_left && go_right) {
-                    push(w.sp, left_first ? right_ref : left_ref, left_first ? right_t : left_t);
-                    w.cur = left_first ? left_ref : right_ref;
-                }
-                else {
-                    w.cur = go_left ? left_ref : right_ref;
-                }
-                need_pop = !go_left && !go_right;
+            n_leaves++;
+            float t_leaf;
+            if(w.cur & PT_REF_SPHERE) {
+                t_leaf = sphere_intersect(v3(q0.x, q0.y, q0.z), q0.w, w.o, w.d);
             }
             else {
                 const TriRec tr = tri_unpack(q0, q1, q2);
                 t_leaf = tri_intersect(tr.a, tr.ab, tr.ac, (tr.obj_cull >> 31) != 0, w.o, w.d);
             }
-        }
-        if(is_leaf) {
-            n_leaves++;
             need_pop = true;
             if(t_leaf >= 0.0f) {
                 if((w.dest & PT_DEST_SHADOW) && t_leaf < w.thr) {
@@ -233,6 +246,9 @@ struct Tracer {
                     break;
                 }
             }
+        }
+        if(w.cur != PT_REF_NONE) {
+            fetch(w, R);
         }
     }
 };
@@ -705,14 +721,14 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
 // ---- the kernel -------------------------------------------------------------------------------------------------------------------------
 
 #ifndef PT_PATH_WAVES
-#define PT_PATH_WAVES 3
+#define PT_PATH_WAVES 4 /* 128 VGPRs: the traversal loop has no spills there; three waves per SIMD hide less of the node-fetch latency (profiles/) */
 #endif
 
 template<int STACK_LDS, bool IN_LDS>
 __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene sc, PtDevCamera cam, PtDevOptions opt, PtSlots S, PtStreams T, PtLocalQueue Q, int rows,
                                                                     int refill_idle, int min_ready, int burst_steps, int leaf_min, uint2 *__restrict__ spill,
-                                                                    uint32_t spill_depth, float4 *__restrict__ image, PtDevCounters *counters,
-                                                                    unsigned long long *__restrict__ wave_counters) {
+                                                                    uint32_t spill_depth, uint32_t *__restrict__ walk_save, uint32_t save_stride, float4 *__restrict__ image,
+                                                                    PtDevCounters *counters, unsigned long long *__restrict__ wave_counters) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // LDS of the workgroup: traversal stacks [STACK_LDS][256] | hit records [4 waves][rows * 64] | slot words [4 waves][rows * 64] |
     // (small scenes) the whole tree and all triangle records
@@ -778,6 +794,8 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene 
     w.cur = PT_REF_NONE;
     w.sp = 0;
     w.occluded = false;
+    typename Tracer<STACK_LDS, IN_LDS>::Rec rec;
+    rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0, n_samples = 0, n_vertices = 0;
     uint32_t w_steps = 0, w_passes = 0; // wave-level diagnostics (same value in every lane)
 #ifdef PT_PATH_TIMING
@@ -818,6 +836,30 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene 
 #ifdef PT_PATH_TIMING
                     const unsigned long long t_pass = __builtin_amdgcn_s_memtime();
 #endif
+                    // Nothing of the traversal lives in registers across a shading pass (which needs them all): the walks in progress
+                    // and the lane's counters are parked in this lane's column of the save area and read back afterwards, so that the
+                    // traversal loop itself never has to spill.
+                    {
+                        uint32_t *sv = walk_save + (size_t)wave * 64 + lane;
+                        const size_t st = save_stride;
+                        sv[0 * st] = __float_as_uint(w.o.x);
+                        sv[1 * st] = __float_as_uint(w.o.y);
+                        sv[2 * st] = __float_as_uint(w.o.z);
+                        sv[3 * st] = __float_as_uint(w.d.x);
+                        sv[4 * st] = __float_as_uint(w.d.y);
+                        sv[5 * st] = __float_as_uint(w.d.z);
+                        sv[6 * st] = __float_as_uint(w.thr);
+                        sv[7 * st] = w.dest;
+                        sv[8 * st] = __float_as_uint(w.best_t);
+                        sv[9 * st] = w.best_ref;
+                        sv[10 * st] = __float_as_uint(w.t_max);
+                        sv[11 * st] = w.cur;
+                        sv[12 * st] = w.sp | (w.occluded ? 0x80000000u : 0u);
+                        sv[13 * st] = n_nodes;
+                        sv[14 * st] = n_leaves;
+                        sv[15 * st] = n_rays;
+                        sv[16 * st] = n_shadow;
+                    }
 #pragma unroll 1
                     for(uint32_t r = 0; r < (uint32_t)rows; r++) {
                         shade_row(sc, cam, opt, S, T, Q, ctx, r, lane, slot_base, queue_base, word_l, hit_l, image, counters, n_samples, n_vertices);
@@ -825,9 +867,34 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene 
                     // the rays just written are read back by other lanes of this wavefront
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                     __builtin_amdgcn_s_waitcnt(0);
+                    {
+                        const uint32_t *sv = walk_save + (size_t)wave * 64 + lane;
+                        const size_t st = save_stride;
+                        w.o = v3(__uint_as_float(sv[0 * st]), __uint_as_float(sv[1 * st]), __uint_as_float(sv[2 * st]));
+                        w.d = v3(__uint_as_float(sv[3 * st]), __uint_as_float(sv[4 * st]), __uint_as_float(sv[5 * st]));
+                        w.inv = slab_inverse(w.d);
+                        w.thr = __uint_as_float(sv[6 * st]);
+                        w.dest = sv[7 * st];
+                        w.best_t = __uint_as_float(sv[8 * st]);
+                        w.best_ref = sv[9 * st];
+                        w.t_max = __uint_as_float(sv[10 * st]);
+                        w.cur = sv[11 * st];
+                        const uint32_t packed = sv[12 * st];
+                        w.sp = packed & 0x7fffffffu;
+                        w.occluded = (packed >> 31) != 0;
+                        n_nodes = sv[13 * st];
+                        n_leaves = sv[14 * st];
+                        n_rays = sv[15 * st];
+                        n_shadow = sv[16 * st];
+                    }
 #ifdef PT_PATH_TIMING
                     t_shade += __builtin_amdgcn_s_memtime() - t_pass;
 #endif
+                    // the record registers do not live across a shading pass: walks in progress fetch theirs again
+                    rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+                    if(active && w.cur != PT_REF_NONE) {
+                        tr.fetch(w, rec);
+                    }
                 }
             }
             if(ctx.q_count > 0) {
@@ -840,7 +907,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene 
                         const float4 ro = Q.ray_o[queue_base + i];
                         const float4 rd = Q.ray_d[queue_base + i];
                         if(__float_as_uint(rd.w) != PT_DEST_NULL) {
-                            tr.start(w, sc, ro, rd);
+                            tr.start(w, rec, sc, ro, rd);
                             active = true;
                             n_rays++;
                             n_shadow += (w.dest & PT_DEST_SHADOW) ? 1u : 0u;
@@ -876,7 +943,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene 
             const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
             w_steps++;
             if(standing && (!at_leaf || do_leaves)) {
-                tr.step(w, n_nodes, n_leaves);
+                tr.step(w, rec, n_nodes, n_leaves);
             }
         }
 #ifdef PT_PATH_TIMING
@@ -948,10 +1015,12 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
     }
     const float *r = rays6 + 6 * gid;
     Walk w;
-    tr.start(w, sc, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
+    typename Tracer<STACK_LDS, IN_LDS>::Rec rec;
+    rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    tr.start(w, rec, sc, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
     uint32_t n_nodes = 0, n_leaves = 0;
     while(w.cur != PT_REF_NONE) {
-        tr.step(w, n_nodes, n_leaves);
+        tr.step(w, rec, n_nodes, n_leaves);
     }
     out[gid] = make_uint2(__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref);
 }
@@ -960,7 +1029,7 @@ template<int STACK_LDS, bool IN_LDS>
 void launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams, PtLocalQueue queue,
                  const PtPathConfig &cfg, float4 *image, PtDevCounters *counters) {
     hipLaunchKernelGGL((pt_path_kernel<STACK_LDS, IN_LDS>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, camera, options, slots, streams, queue, cfg.rows,
-                       cfg.refill_idle, cfg.min_ready, cfg.burst_steps, cfg.leaf_min, cfg.spill, cfg.spill_depth, image, counters, cfg.wave_counters);
+                       cfg.refill_idle, cfg.min_ready, cfg.burst_steps, cfg.leaf_min, cfg.spill, cfg.spill_depth, cfg.walk_save, (uint32_t)cfg.grid * 256u, image, counters, cfg.wave_counters);
 }
 
 template<int STACK_LDS, bool IN_LDS>

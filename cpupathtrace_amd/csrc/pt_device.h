@@ -314,14 +314,16 @@ PT_D Ray bsdf_propagate(const Material &m, V3 ray_d, V3 pos, V3 normal, float ep
     Ray out;
     if(m.bsdf == 0) {
         // importanceSampleCosine(dist(re), dist(re), 1.0F): clang evaluates the arguments left to right, r1 first.
-        // With e = 1: pow(r2, 2/(e+1)) = pow(r2, 1) = r2 exactly, pow(cos_theta, e) = cos_theta exactly.
+        // With e = 1: pow(r2, 2/(e+1)) = pow(r2, 1) and pow(cos_theta, e) = pow(cos_theta, 1): the reference's build has these folded to
+        // their first argument (and glibc's powf(x, 1) returns x for every x in [0, 1]: tests/test_abi_cpu.py), so no powf is evaluated
+        // for them; pow(r2, 1/(e+1)) = powf(r2, 0.5f) is a real call there (and differs from sqrtf for 0.064 % of the inputs).
         float r1 = rng_uniform01(rng);
         float r2 = rng_uniform01(rng);
-        float fac = __builtin_sqrtf(1.0f - ptm::powf_glibc(r2, 1.0f));
+        float fac = __builtin_sqrtf(1.0f - r2);
         float cos_theta = ptm::powf_glibc(r2, 0.5f);
         float phi = 2.0f * PT_PI_F * r1;
         V3 local_dir = v3(fac * ptm::cosf_glibc(phi), fac * ptm::sinf_glibc(phi), cos_theta);
-        float p = (1.0f + 1) * ptm::powf_glibc(cos_theta, 1.0f) / (2.0f * PT_PI_F);
+        float p = (1.0f + 1) * cos_theta / (2.0f * PT_PI_F);
         V3 dir = local_to_global(local_dir, normal);
         out.o = pos + dir * epsilon;
         out.d = dir;

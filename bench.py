@@ -314,17 +314,17 @@ def run_rank(args):
         if device.type == "cuda":
             torch.cuda.synchronize()
 
-    # the timed steps run the product's default path (no per-launch statistics); the work counters the roofline needs come from
-    # the kernel's own counters of one extra, untimed step afterwards
+    # A step is one launch of the path kernel per rank.  Asking for statistics does not change the launch: the kernel always counts its
+    # work in per-wave registers; the library then reads two HIP events recorded around the launch and the counters (128 KB) back.
     for _ in range(args.warmup):
         job.render()
     sync()
     t0 = time.perf_counter()
+    stats = None
     for _ in range(args.steps):
-        job.render()
+        stats = job.render(want_stats=not standin)
     sync()
     elapsed = time.perf_counter() - t0
-    stats = None if standin else job.render(want_stats=True)
     my_pixels = int(sum(int(t["w"]) * int(t["h"]) for t in job.mine))
     mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "tiles": int(job.n_local_tiles), "pixels": my_pixels, "elapsed_s": elapsed,
             "device_name": torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu",
@@ -370,34 +370,32 @@ def run_rank(args):
 
 
 def roofline(s, args, msamples_per_s, world):
-    """Dominant kernel.  `achieved` / `frac` are SURVEY.md 8(d)'s figure: ALGORITHMIC bytes (the formula, with the kernel's own work counters)
-    divided by the time the kernel runs (HIP events on its stream), against the HBM peak -- a work rate, NOT a bandwidth
-    utilisation.  What the memory system actually moves is reported next to it: `traffic` (PMC, per launch), `hbm_frac` (PMC bytes at
-    this run's sample rate / 8 TB/s) and `l2_frac` (algorithmic bytes at this rate / the L2's 34.5 TB/s: every node record that is
-    not an L1 hit comes from there).  `bound` says what the counters say (profiles/): dependent-fetch latency, not bandwidth."""
+    """Dominant kernel = pt_path_kernel, ONE launch per step.  `achieved` / `frac` are SURVEY.md 8(d)'s figure: ALGORITHMIC bytes per launch
+    (the formula, with the kernel's own work counters of that launch) divided by the launch's duration (HIP events on the library's
+    stream around the launch, last timed step), against the HBM peak -- a work rate, NOT a bandwidth utilisation.  What the memory
+    system actually moves is reported next to it: `traffic` (PMC bytes per launch, from profiles/), `hbm_frac` (PMC bytes per second /
+    8 TB/s) and `l2_frac` (algorithmic bytes per second / the L2's 34.5 TB/s: every node record that is not an L1 hit comes from
+    there).  `bound` says what the counters say (profiles/): dependent record fetches in SIMT lockstep, not bandwidth."""
     samples = max(s["samples"], 1)
     R = s["rays_traced"] / samples
     A = (2.0 * s["node_visits"] + s["rays_traced"]) / max(s["rays_traced"], 1)  # two slab tests per inner node + the root test
     T = s["leaf_tests"] / max(s["rays_traced"], 1)
     V = s["vertices"] / samples
     bytes_per_sample = ref_formula_bytes_per_sample(R, A, T, V)
-    launches = max(s["iterations"], 1)
-    kernel_s = max(s.get("trace_busy_ms", s["trace_ms"]), 1e-6) / 1e3   # time during which the kernel runs (union over concurrent launches)
+    launches = max(s["launches"], 1)
+    kernel_s = max(s["kernel_ms"], 1e-6) / 1e3
     achieved = bytes_per_sample * samples / kernel_s / 1e9
     per_sample, source = measured_traffic("%s-%d" % (args.workload, args.mesh_n if args.workload.startswith("dragon") else 0))
-    per_gpu_rate = msamples_per_s * 1e6 / world
-    out = {"bound": "latency", "bound_note": "dependent node fetches in SIMT lockstep; HBM and L2 bandwidth are far from saturated (hbm_frac, l2_frac)",
-           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": per_sample * samples / launches if per_sample else None, "traffic_source": source,
-           "kernel": s.get("kernel", "pt_trace_kernel"), "launches_per_step": launches, "avg_launch_ms": s["trace_ms"] / launches,
-           "algorithmic_bytes_per_launch": bytes_per_sample * samples / launches, "algorithmic_bytes_per_sample": bytes_per_sample,
-           "frac_per_launch": bytes_per_sample * samples / launches / max(s["trace_ms"] / launches / 1e3, 1e-9) / 1e9 / HBM_PEAK_GBS,
-           "hbm_frac": (per_sample * per_gpu_rate / 1e9 / HBM_PEAK_GBS) if per_sample else None,
-           "l2_frac": bytes_per_sample * per_gpu_rate / 1e9 / L2_PEAK_GBS,
-           "per_sample": {"rays": R, "aabb_tests_per_ray": A, "leaf_tests_per_ray": T, "vertices": V},
-           "kernel_ms": s["trace_ms"], "kernel_busy_ms": kernel_s * 1e3, "shade_ms": s["shade_ms"], "step_device_ms": s["total_ms"],
-           "stream_groups": s.get("groups", 1)}
-    return out
+    return {"bound": "latency", "bound_note": "dependent record fetches in SIMT lockstep at 4 waves per SIMD; HBM and L2 bandwidth are far from saturated (hbm_frac, l2_frac)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": per_sample * samples / launches if per_sample else None, "traffic_source": source,
+            "kernel": "pt_path_kernel", "launches_per_step": launches, "avg_launch_ms": s["kernel_ms"] / launches,
+            "algorithmic_bytes_per_launch": bytes_per_sample * samples / launches, "algorithmic_bytes_per_sample": bytes_per_sample,
+            "hbm_frac": (per_sample * samples / kernel_s / 1e9 / HBM_PEAK_GBS) if per_sample else None,
+            "l2_frac": achieved / L2_PEAK_GBS,
+            "per_sample": {"rays": R, "aabb_tests_per_ray": A, "leaf_tests_per_ray": T, "vertices": V},
+            "wavefronts": s["wavefronts"], "slot_rows": s["slot_rows"], "wave_steps": s["wave_steps"], "shading_passes": s["shading_passes"],
+            "walks_per_wave_step": (s["node_visits"] + s["leaf_tests"]) / max(s["wave_steps"], 1)}
 
 
 def main():

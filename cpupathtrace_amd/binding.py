@@ -21,7 +21,7 @@ PT_OK = 0
 ERRORS = {1: "PT_ERR_INVALID", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR_HIP", 4: "PT_ERR_UNSUPPORTED", 5: "PT_ERR_NOMEM"}
 
 EXPORTS = ["pt_device_count", "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_scene_info", "pt_scene_emissive", "pt_scene_bvh_dump", "pt_intersect_batch",
-           "pt_render_streams", "pt_render_tiles", "pt_render_tiles_progress", "pt_render_tiles_device", "pt_job_tiles", "pt_pixel_seed", "pt_rng_seed_to_state", "pt_post_process", "pt_post_process_device"]
+           "pt_render_streams", "pt_render_item", "pt_render_tiles", "pt_render_tiles_progress", "pt_render_tiles_multi", "pt_render_tiles_device", "pt_job_tiles", "pt_pixel_seed", "pt_rng_seed_to_state", "pt_post_process", "pt_post_process_device"]
 
 
 class PtError(RuntimeError):
@@ -63,8 +63,8 @@ class Options(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_traced", C.c_uint64), ("shadow_rays_traced", C.c_uint64), ("node_visits", C.c_uint64),
-                ("leaf_tests", C.c_uint64), ("vertices", C.c_uint64), ("iterations", C.c_uint64), ("trace_ms", C.c_double),
-                ("shade_ms", C.c_double), ("total_ms", C.c_double), ("trace_busy_ms", C.c_double), ("groups", C.c_uint64)]
+                ("leaf_tests", C.c_uint64), ("vertices", C.c_uint64), ("launches", C.c_uint64), ("kernel_ms", C.c_double),
+                ("wave_steps", C.c_uint64), ("shading_passes", C.c_uint64), ("wavefronts", C.c_uint64), ("slot_rows", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -232,6 +232,29 @@ class Scene:
                                       C.byref(st) if want_stats else None))
         return (image, st.as_dict()) if want_stats else image
 
+    def process_work_item(self, camera, options, x, y, w, h, rng_state, want_stats=False):
+        """processItem(WorkItem(job, x, y, w, h), engine) returning the item's own (h, w, 4) tile and the engine state afterwards."""
+        item = np.zeros(1, dtype=STREAM_DTYPE)
+        item["x"], item["y"], item["w"], item["h"], item["rng_state"] = x, y, w, h, rng_state
+        tile = np.zeros((max(h, 0), max(w, 0), 4), np.float32)
+        state = C.c_uint64()
+        cp, op, st = _camera(camera), _options(options), Stats()
+        _check(load().pt_render_item(self._h, C.byref(cp), C.byref(op), _ptr(item), _ptr(tile) if tile.size else None, C.byref(state),
+                                     C.byref(st) if want_stats else None))
+        return (tile, state.value, st.as_dict()) if want_stats else (tile, state.value)
+
+    def process_job_progress(self, camera, options, progress, base_seed=1234, tiles=None):
+        """processJob with its progress callback (worker.h:75-84): progress(completed, total) from the calling thread while the device renders."""
+        if tiles is None:
+            tiles = job_tiles(options["image_width"], options["image_height"])
+        tiles = np.ascontiguousarray(tiles, dtype=TILE_DTYPE)
+        image = np.zeros((options["image_height"], options["image_width"], 4), np.float32)
+        cb = PROGRESS_FN(lambda done, total, user: progress(done, total))
+        cp, op = _camera(camera), _options(options)
+        _check(load().pt_render_tiles_progress(self._h, C.byref(cp), C.byref(op), _ptr(tiles), C.c_size_t(len(tiles)), C.c_uint64(base_seed), _ptr(image), None,
+                                               cb, None))
+        return image
+
     def process_job_device(self, camera, options, d_image_ptr, stream_ptr, base_seed=1234, tiles=None, want_stats=False):
         """processJob writing into device memory (d_image_ptr: device address of width*height*4 floats)."""
         if tiles is None:
@@ -241,6 +264,24 @@ class Scene:
         _check(load().pt_render_tiles_device(self._h, C.byref(cp), C.byref(op), _ptr(tiles), C.c_size_t(len(tiles)), C.c_uint64(base_seed),
                                              C.c_void_p(d_image_ptr), C.c_void_p(stream_ptr), C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_void_p)
+
+
+def process_job_multi(scenes, camera, options, base_seed=1234, tiles=None, progress=None, want_stats=False):
+    """processJob over several Scene replicas (one per device): tile k is rendered by scenes[k % len(scenes)]."""
+    if tiles is None:
+        tiles = job_tiles(options["image_width"], options["image_height"])
+    tiles = np.ascontiguousarray(tiles, dtype=TILE_DTYPE)
+    image = np.zeros((options["image_height"], options["image_width"], 4), np.float32)
+    handles = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    stats = (Stats * len(scenes))()
+    cb = PROGRESS_FN(lambda done, total, user: progress(done, total)) if progress is not None else None
+    cp, op = _camera(camera), _options(options)
+    _check(load().pt_render_tiles_multi(handles, C.c_int(len(scenes)), C.byref(cp), C.byref(op), _ptr(tiles), C.c_size_t(len(tiles)), C.c_uint64(base_seed),
+                                        _ptr(image), stats if want_stats else None, cb, None))
+    return (image, [s.as_dict() for s in stats]) if want_stats else image
 
 
 def pixel_streams(xs, ys, states):

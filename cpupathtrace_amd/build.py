@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpathtrace_hip.so")
-SOURCES = ["pt_api.cpp", "pt_bvh.cpp", "pt_build.hip", "pt_post.hip", "pt_trace.hip", "pt_shade.hip", "pt_path.hip"]
+SOURCES = ["pt_api.cpp", "pt_bvh.cpp", "pt_build.hip", "pt_post.hip", "pt_path.hip"]
 HEADERS = ["pt_build.h", "pt_post.h", "pt_types.h", "pt_kernels.h", "pt_device.h", "pt_shading.h", "pt_libm.h", "pt_bvh.h", os.path.join("..", "..", "include", "pt_hip.h")]
 
 # -ffp-contract=off + correctly rounded divide/sqrt: every fp32/fp64 operation is the IEEE operation the reference's

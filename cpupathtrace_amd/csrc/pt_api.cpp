@@ -1,8 +1,8 @@
 // pt_api.cpp -- host side of libpathtrace_hip.so: the C ABI of include/pt_hip.h.
 //
 // Scene creation flattens the caller's object list into the HBM layout of pt_types.h (building the reference's BVH
-// topology on the way, pt_bvh.cpp); rendering drives the wavefront loop: shade -> trace -> shade -> ... until every stream
-// has rendered all its pixels.  There is no CPU rendering path in this library.
+// topology on the way, pt_bvh.cpp / pt_build.hip); a render call is ONE launch of the persistent path kernel (pt_path.hip), whose
+// wavefronts render the call's streams until none is left.  There is no CPU rendering path in this library.
 #include "../../include/pt_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -23,8 +23,6 @@
 #include "pt_bvh.h"
 #include "pt_kernels.h"
 #include "pt_post.h"
-
-#define PT_MAX_GROUPS 8 /* independent slices of the streams pipelined on separate HIP streams */
 
 namespace {
 
@@ -151,52 +149,22 @@ struct pt_scene {
     std::vector<float> emissive_cdf;
 
     // device scene
-    DevBuf<F4> pairs, quads, tris, tri_shade, spheres, materials, lights, emis;
+    DevBuf<F4> pairs, tris, tri_shade, spheres, materials, lights, emis;
     DevBuf<uint2> sph_meta;
     DevBuf<float> emis_cdf;
     PtDevScene dev{};
 
-    // render workspace (grown on demand, reused between calls)
-    uint32_t ws_slots = 0;
-    DevBuf<int4> rect;
-    DevBuf<uint64_t> rng;
-    DevBuf<int32_t> cursor, path_length;
-    DevBuf<uint32_t> flags, nee_mask, vis;
-    DevBuf<F4> ray_o, ray_d, spectrum, out, nee;
-    DevBuf<double> divisor, bounce_pd;
-    DevBuf<PtEstimator> est;
-    DevBuf<PtCandidate> cand;
-    DevBuf<uint2> hit;
-    DevBuf<F4> q_ray_o, q_ray_d;
-    DevBuf<uint32_t> q_header; // count[8], head[8], each word on its own 256-byte line
-    DevBuf<uint2> spill;
     DevBuf<PtDevCounters> counters;
     DevBuf<F4> image;
     DevBuf<int4> tiles;
     DevBuf<uint32_t> tile_offset;
     DevBuf<float> batch_rays;
-    DevBuf<uint32_t> walk_hist;
-    DevBuf<unsigned long long> shade_wave_counters, trace_wave_counters;
-    hipEvent_t check_event[2 * PT_MAX_GROUPS] = {};
-    // suspended walks: two pools per group
-    DevBuf<F4> carry_o, carry_d;
-    DevBuf<uint4> carry_state;
-    DevBuf<uint32_t> carry_sp, carry_header;
-    DevBuf<uint2> carry_stack;
-    uint32_t carry_cap = 0; // per pool
-    uint32_t shard_capacity = 0;   // per group
-    uint32_t ws_groups = 1;        // groups the queue / spill / counter buffers are sized for
-    PtTraceConfig trace_cfg{};
-    PtDevCounters *host_counters = nullptr; // pinned, 2 x PT_MAX_GROUPS entries (the done-check reads the previous batch's copy)
-    hipStream_t group_stream[PT_MAX_GROUPS] = {};
-    uint32_t concurrent_streams = 0; // group streams found to run side by side (pick_concurrent_streams)
 
     // One render call at a time per scene: the workspace below is shared by every entry point (processItem may be called from several
     // threads on one const Scene, reference worker.h:66-69 / src/worker.cpp:328-362: such callers are serialised here).
     std::mutex render_mutex;
 
-    // workspace of the persistent path kernel (pt_path.hip)
-    bool use_path = true;
+    // workspace of the persistent path kernel (pt_path.hip), grown on demand and reused between calls
     PtPathConfig path_cfg{};
     int path_blocks_per_cu = 0;
     uint32_t path_slots = 0, path_waves = 0, path_cap = 0;
@@ -214,22 +182,8 @@ struct pt_scene {
     uint32_t *host_tiles_done = nullptr; // pinned: tiles finished so far, written by the kernel (progress callback)
 
     ~pt_scene() {
-        if(host_counters != nullptr) {
-            (void)hipHostFree(host_counters);
-        }
         if(host_tiles_done != nullptr) {
             (void)hipHostFree(host_tiles_done);
-        }
-        for(hipEvent_t e : check_event) {
-            if(e != nullptr) {
-                (void)hipEventDestroy(e);
-            }
-        }
-        for(size_t g = 0; g < PT_MAX_GROUPS; g++) {
-            // (later entries may repeat an earlier stream when the runtime offered fewer concurrent ones than groups)
-            if(group_stream[g] != nullptr && std::find(group_stream, group_stream + g, group_stream[g]) == group_stream + g) {
-                (void)hipStreamDestroy(group_stream[g]);
-            }
         }
         if(stream != nullptr) {
             (void)hipStreamDestroy(stream);
@@ -246,232 +200,6 @@ int device_count_quiet() {
         return 0;
     }
     return n;
-}
-
-// view of the slots [start, start + n) of the workspace
-PtPaths make_paths(pt_scene *s, uint32_t n, uint32_t start = 0) {
-    PtPaths P{};
-    P.n = n;
-    P.rect = s->rect.ptr + start;
-    P.rng = s->rng.ptr + start;
-    P.cursor = s->cursor.ptr + start;
-    P.flags = s->flags.ptr + start;
-    P.ray_o = reinterpret_cast<float4 *>(s->ray_o.ptr) + start;
-    P.ray_d = reinterpret_cast<float4 *>(s->ray_d.ptr) + start;
-    P.spectrum = reinterpret_cast<float4 *>(s->spectrum.ptr) + start;
-    P.out = reinterpret_cast<float4 *>(s->out.ptr) + start;
-    P.divisor = s->divisor.ptr + start;
-    P.bounce_pd = s->bounce_pd.ptr + start;
-    P.path_length = s->path_length.ptr + start;
-    P.nee = reinterpret_cast<float4 *>(s->nee.ptr) + start;
-    P.nee_stride = s->ws_slots;
-    P.nee_mask = s->nee_mask.ptr + start;
-    P.est = s->est.ptr + start;
-    P.cand = s->cand.ptr + static_cast<size_t>(start) * PT_MAX_CANDIDATES;
-    P.hit = s->hit.ptr + start;
-    P.vis = s->vis.ptr + start;
-    P.wave_counters = s->shade_wave_counters.ptr + 2 * static_cast<size_t>(start / 64);
-    return P;
-}
-
-PtQueue make_queue(pt_scene *s, uint32_t group = 0) {
-    PtQueue q{};
-    const size_t rays = static_cast<size_t>(s->shard_capacity) * PT_SHARDS;
-    q.ray_o = reinterpret_cast<float4 *>(s->q_ray_o.ptr) + group * rays;
-    q.ray_d = reinterpret_cast<float4 *>(s->q_ray_d.ptr) + group * rays;
-    // two headers per group (count[8] + head[8] words each), used by alternate launches
-    q.count = s->q_header.ptr + static_cast<size_t>(group) * 4 * PT_SHARDS * PT_QSTRIDE;
-    q.head = q.count + PT_SHARDS * PT_QSTRIDE;
-    q.next_header = nullptr;
-    q.shard_capacity = s->shard_capacity;
-    return q;
-}
-
-PtCarry make_carry(pt_scene *s, uint32_t group = 0) {
-    PtCarry c{};
-    const size_t base = static_cast<size_t>(group) * 2 * s->carry_cap;
-    c.ray_o = reinterpret_cast<float4 *>(s->carry_o.ptr) + base;
-    c.ray_d = reinterpret_cast<float4 *>(s->carry_d.ptr) + base;
-    c.state = s->carry_state.ptr + base;
-    c.sp = s->carry_sp.ptr + base;
-    c.depth = std::max<uint32_t>(s->depth, 1U);
-    c.stack = s->carry_stack.ptr + base * c.depth;
-    c.count = s->carry_header.ptr + static_cast<size_t>(group) * 4 * PT_QSTRIDE;
-    c.head = c.count + 2 * PT_QSTRIDE;
-    c.cap = s->carry_cap;
-    return c;
-}
-
-// Group streams that really run side by side.  The runtime multiplexes HIP streams onto a few hardware queues (four by default),
-// and kernels of two streams that share a queue run one after the other -- which stream lands on which queue depends on what else
-// the process has created.  Candidates are therefore PROBED: a 400 us do-nothing kernel on each of two streams takes 400 us when
-// they are concurrent and 800 us when they are not.  `wanted` streams that are pairwise concurrent are kept; if the runtime offers
-// fewer, the later groups share the last stream found (they then simply queue up).
-int pick_concurrent_streams(pt_scene *s, uint32_t wanted) {
-    using clock = std::chrono::steady_clock;
-    std::vector<hipStream_t> candidates, chosen;
-    for(hipStream_t gs : s->group_stream) {
-        if(gs != nullptr && std::find(chosen.begin(), chosen.end(), gs) == chosen.end()) {
-            chosen.push_back(gs); // streams picked earlier stay
-        }
-    }
-    auto concurrent = [&](hipStream_t a, hipStream_t b, bool &result) -> int {
-        double best = 1e30;
-        for(int attempt = 0; attempt < 2; attempt++) { // the faster of two tries: a slow first launch must not look like queueing
-            PT_HIP(hipStreamSynchronize(a));
-            PT_HIP(hipStreamSynchronize(b));
-            const auto t0 = clock::now();
-            pt_launch_spin(a, 400);
-            pt_launch_spin(b, 400);
-            PT_HIP(hipStreamSynchronize(a));
-            PT_HIP(hipStreamSynchronize(b));
-            best = std::min(best, std::chrono::duration<double, std::micro>(clock::now() - t0).count());
-        }
-        result = best < 650.0;
-        return PT_OK;
-    };
-    const int max_candidates = 12;
-    for(int i = 0; i < max_candidates && chosen.size() < wanted; i++) {
-        hipStream_t c = nullptr;
-        PT_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
-        candidates.push_back(c);
-        pt_launch_spin(c, 1); // first use of a stream may create its queue: keep that out of the probe
-        bool ok = true;
-        for(hipStream_t other : chosen) {
-            bool side_by_side = false;
-            int rc = concurrent(c, other, side_by_side);
-            if(rc != PT_OK) {
-                return rc;
-            }
-            if(!side_by_side) {
-                ok = false;
-                break;
-            }
-        }
-        if(ok) {
-            chosen.push_back(c);
-        }
-    }
-    for(hipStream_t c : candidates) {
-        if(std::find(chosen.begin(), chosen.end(), c) == chosen.end()) {
-            (void)hipStreamDestroy(c);
-        }
-    }
-    s->concurrent_streams = static_cast<uint32_t>(chosen.size());
-    for(uint32_t g = 0; g < PT_MAX_GROUPS; g++) {
-        s->group_stream[g] = chosen.empty() ? nullptr : (g < chosen.size() ? chosen[g] : (g < wanted ? chosen.back() : nullptr));
-    }
-    if(env_int("PT_DEBUG", 0) != 0) {
-        std::fprintf(stderr, "[pt] %zu of %u wanted group streams run concurrently (probed %zu candidates)\n", chosen.size(), wanted, candidates.size());
-    }
-    return chosen.empty() ? fail(PT_ERR_HIP, "no usable HIP stream") : PT_OK;
-}
-
-// workspace for n stream slots and a queue of `queue_rays_per_slot` rays per slot
-int ensure_workspace(pt_scene *s, uint32_t n, uint32_t rays_per_slot, uint32_t groups = 1) {
-    // each group holds ceil(n / groups) slots (rounded up to whole 2048-slot units, see group_ranges)
-    const uint32_t per_group = ((n + groups - 1) / groups + 2047U) / 2048U * 2048U;
-    const uint32_t blocks = (per_group + 255) / 256;
-    const uint32_t blocks_per_shard = (blocks + PT_SHARDS - 1) / PT_SHARDS;
-    const uint32_t cap = std::max<uint32_t>(blocks_per_shard * 256U * rays_per_slot, 256U);
-    PT_HIP(s->rect.ensure(n));
-    PT_HIP(s->rng.ensure(n));
-    PT_HIP(s->cursor.ensure(n));
-    PT_HIP(s->path_length.ensure(n));
-    PT_HIP(s->flags.ensure(n));
-    PT_HIP(s->nee_mask.ensure(n));
-    PT_HIP(s->vis.ensure(static_cast<size_t>(n) * PT_MAX_NEE));
-    PT_HIP(s->ray_o.ensure(n));
-    PT_HIP(s->ray_d.ensure(n));
-    PT_HIP(s->spectrum.ensure(n));
-    PT_HIP(s->out.ensure(n));
-    PT_HIP(s->nee.ensure(static_cast<size_t>(n) * PT_MAX_NEE));
-    PT_HIP(s->divisor.ensure(n));
-    PT_HIP(s->bounce_pd.ensure(n));
-    PT_HIP(s->est.ensure(n));
-    PT_HIP(s->cand.ensure(static_cast<size_t>(n) * PT_MAX_CANDIDATES));
-    PT_HIP(s->hit.ensure(n));
-    // `nee` is addressed as [plane][slot] with the allocation's slot count as stride: keep the stride in step with it
-    s->ws_slots = static_cast<uint32_t>(std::min<size_t>(s->nee.count / PT_MAX_NEE, 0xffffffffu));
-    const size_t want_rays = static_cast<size_t>(cap) * PT_SHARDS * groups;
-    if(s->q_ray_o.count < want_rays || s->ws_groups != groups || s->shard_capacity < cap) {
-        PT_HIP(s->q_ray_o.ensure(want_rays));
-        PT_HIP(s->q_ray_d.ensure(want_rays));
-        s->shard_capacity = cap;
-        s->ws_groups = groups;
-    }
-    PT_HIP(s->q_header.ensure(static_cast<size_t>(PT_MAX_GROUPS) * 4 * PT_SHARDS * PT_QSTRIDE));
-    PT_HIP(s->counters.ensure(PT_MAX_GROUPS));
-    PT_HIP(s->shade_wave_counters.ensure(2 * (static_cast<size_t>(n) / 64 + PT_MAX_GROUPS)));
-    PT_HIP(s->trace_wave_counters.ensure(static_cast<size_t>(s->trace_cfg.grid) * 4 * 8 * groups));
-    PT_HIP(s->spill.ensure(static_cast<size_t>(s->trace_cfg.grid) * 256 * s->trace_cfg.spill_depth * groups));
-    {
-        // room for a quarter of a group's rays to be suspended at once (a full pool only means walks are not suspended)
-        const uint32_t want_cap = std::max<uint32_t>(4096U, per_group / 4U * rays_per_slot);
-        if(s->carry_cap < want_cap || s->carry_o.count < static_cast<size_t>(want_cap) * 2 * groups) {
-            s->carry_cap = std::max(s->carry_cap, want_cap);
-            const size_t total = static_cast<size_t>(s->carry_cap) * 2 * PT_MAX_GROUPS;
-            PT_HIP(s->carry_o.ensure(total));
-            PT_HIP(s->carry_d.ensure(total));
-            PT_HIP(s->carry_state.ensure(total));
-            PT_HIP(s->carry_sp.ensure(total));
-            PT_HIP(s->carry_stack.ensure(total * std::max<uint32_t>(s->depth, 1U)));
-        }
-        PT_HIP(s->carry_header.ensure(static_cast<size_t>(PT_MAX_GROUPS) * 4 * PT_QSTRIDE));
-    }
-    s->trace_cfg.spill = s->spill.ptr;
-    if(env_int("PT_WALK_HIST", 0) != 0 && s->walk_hist.ptr == nullptr) {
-        PT_HIP(s->walk_hist.ensure(64));
-        PT_HIP(hipMemset(s->walk_hist.ptr, 0, 64 * sizeof(uint32_t)));
-        s->trace_cfg.walk_hist = s->walk_hist.ptr;
-    }
-    if(s->host_counters == nullptr) {
-        PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->host_counters), sizeof(PtDevCounters) * 2 * PT_MAX_GROUPS, hipHostMallocDefault));
-        for(auto &e : s->check_event) {
-            PT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-    }
-    if(groups > 1 && s->group_stream[groups - 1] == nullptr) {
-        int rc = pick_concurrent_streams(s, groups);
-        if(rc != PT_OK) {
-            return rc;
-        }
-    }
-    else if(s->group_stream[0] == nullptr) {
-        PT_HIP(hipStreamCreateWithFlags(&s->group_stream[0], hipStreamNonBlocking));
-    }
-    return PT_OK;
-}
-
-int setup_trace(pt_scene *s) {
-    PtTraceConfig &cfg = s->trace_cfg;
-    if(cfg.grid != 0) {
-        return PT_OK;
-    }
-    int stack_lds = env_int("PT_STACK_LDS", 16);
-    if(stack_lds != 8 && stack_lds != 16 && stack_lds != 24) {
-        stack_lds = 16;
-    }
-    cfg.stack_lds = stack_lds;
-    cfg.lds_mode = (s->dev.n_lds_pairs == 0 && s->dev.n_lds_tris == 0) ? (s->dev.quads != nullptr ? 3 : 0) : ((s->dev.n_lds_pairs == s->dev.n_pairs && s->dev.n_lds_tris == s->dev.n_tris) ? 2 : 1);
-    cfg.lds_bytes = static_cast<size_t>(stack_lds) * 256 * sizeof(uint2) + static_cast<size_t>(s->dev.n_lds_pairs) * 64 + static_cast<size_t>(s->dev.n_lds_tris) * 48;
-    const int per_cu = pt_trace_blocks_per_cu(stack_lds, cfg.lds_mode, cfg.lds_bytes);
-    const int limit = env_int("PT_TRACE_BLOCKS_PER_CU", 0);
-    cfg.grid = s->cu_count * ((limit > 0 && limit < per_cu) ? limit : per_cu);
-    cfg.spill_depth = s->depth > static_cast<uint32_t>(stack_lds) ? s->depth - static_cast<uint32_t>(stack_lds) : 1U;
-    cfg.spill = nullptr; // allocated with the workspace (one area per group)
-    // measured (profiles/): short LDS-resident walks want few dequeue atomics (256 rays each, refill at 20 idle lanes); long walks
-    // through HBM-resident trees want fine-grained balancing between wavefronts (96 rays, refill at 12)
-    const bool small_scene = cfg.lds_mode == 2;
-    cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", small_scene ? 20 : 12), 1), 64);
-    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 1), 1), 64);
-    cfg.chunk = std::min(std::max(env_int("PT_QCHUNK", small_scene ? 256 : 96), 16), 4096);
-    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 4), 1), 64);
-    if(env_int("PT_DEBUG", 0) != 0) {
-        std::fprintf(stderr, "[pt] trace config: grid %d (%d CUs x %d blocks), stack_lds %d, lds mode %d, lds %zu B, spill depth %u, lds pairs %u, lds tris %u\n", cfg.grid,
-                     s->cu_count, per_cu, stack_lds, cfg.lds_mode, cfg.lds_bytes, cfg.spill_depth, s->dev.n_lds_pairs, s->dev.n_lds_tris);
-    }
-    return PT_OK;
 }
 
 PtDevCamera derive_camera(const pt_camera_params *c) {
@@ -531,278 +259,6 @@ int check_render_args(pt_scene *scene, const pt_camera_params *camera, const pt_
     }
     if(options->image_width <= 0 || options->image_height <= 0) {
         return fail(PT_ERR_INVALID, "image size must be positive");
-    }
-    return PT_OK;
-}
-
-// The wavefront loop over an initialised set of `n` stream slots.
-//
-// The slots are cut into up to PT_MAX_GROUPS contiguous groups, each with its own ray queue, counters and HIP stream.  A
-// group's iteration is shade -> trace on its stream; the groups are independent (a ray's destination is a slot of its own
-// group), so the drain phase of one group's persistent traversal kernel -- a few long walks through the glass mesh --
-// overlaps with the other groups' work instead of idling the chip.
-int run_wavefront(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, uint32_t n, uint32_t groups, float4 *d_image, pt_stats *stats) {
-    const uint32_t rays_per_slot = 1U + s->dev.n_lights + s->dev.n_object_samples;
-    struct Group {
-        uint32_t start, count;
-        PtPaths P;
-        PtQueue q;
-        PtCarry carry;
-        PtTraceConfig cfg;
-        hipStream_t st;
-        bool done;
-    };
-    std::vector<Group> G(groups);
-    const int shard_mode = env_int("PT_SHARD_MODE", 1);
-    const int drain_lanes = std::min(std::max(env_int("PT_DRAIN_LANES", 16), 0), 64);
-    const int endgame_percent = std::min(std::max(env_int("PT_ENDGAME_PERCENT", 90), 1), 101);
-    const int max_steps_env = env_int("PT_MAX_STEPS", 256);
-    const int max_steps = max_steps_env > 0 ? max_steps_env : 0x7fffffff;
-    const int group_blocks_per_cu = std::max(env_int("PT_GROUP_BLOCKS_PER_CU", 2), 1);
-    const uint32_t per_group = ((n + groups - 1) / groups + 2047U) / 2048U * 2048U;
-    uint32_t n_groups = 0;
-    for(uint32_t g = 0; g < groups; g++) {
-        const uint32_t begin = std::min<uint64_t>(static_cast<uint64_t>(g) * per_group, n);
-        const uint32_t end = std::min<uint64_t>(static_cast<uint64_t>(g + 1) * per_group, n);
-        if(end <= begin) {
-            break;
-        }
-        Group &gr = G[n_groups];
-        gr.start = begin;
-        gr.count = end - begin;
-        gr.P = make_paths(s, gr.count, begin);
-        gr.q = make_queue(s, n_groups);
-        gr.carry = make_carry(s, n_groups);
-        gr.cfg = s->trace_cfg;
-        gr.cfg.max_steps = max_steps;
-        gr.cfg.drain_lanes = drain_lanes;
-        // no more workgroups than the rays one iteration can produce
-        const uint64_t blocks = (static_cast<uint64_t>(gr.count) * rays_per_slot + 255) / 256;
-        gr.cfg.grid = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(gr.cfg.grid), blocks)));
-        if(groups > 1 && gr.cfg.lds_mode != 2) {
-            // concurrent groups share the CUs: two persistent workgroups per CU each (three groups fill a CU's LDS and wave slots).
-            // (Giving the groups that are still rendering the CUs of the finished ones was measured: no gain -- by then they are in
-            // the latency-bound end of the frame.)
-            gr.cfg.grid = std::min(gr.cfg.grid, s->cu_count * group_blocks_per_cu);
-        }
-        gr.cfg.spill = s->spill.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 256 * s->trace_cfg.spill_depth;
-        gr.cfg.wave_counters = s->trace_wave_counters.ptr + static_cast<size_t>(n_groups) * s->trace_cfg.grid * 32;
-        gr.st = s->group_stream[n_groups];
-        gr.done = false;
-        n_groups++;
-    }
-    G.resize(n_groups);
-
-    // order the groups' streams after the initialisation that ran on the main stream
-    hipEvent_t ev_init;
-    PT_HIP(hipEventCreateWithFlags(&ev_init, hipEventDisableTiming));
-    PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters) * PT_MAX_GROUPS, s->stream));
-    PT_HIP(hipMemsetAsync(s->carry_header.ptr, 0, static_cast<size_t>(PT_MAX_GROUPS) * 4 * PT_QSTRIDE * sizeof(uint32_t), s->stream));
-    PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, s->q_header.count * sizeof(uint32_t), s->stream));
-    PT_HIP(hipMemsetAsync(s->shade_wave_counters.ptr, 0, s->shade_wave_counters.count * sizeof(unsigned long long), s->stream));
-    PT_HIP(hipMemsetAsync(s->trace_wave_counters.ptr, 0, s->trace_wave_counters.count * sizeof(unsigned long long), s->stream));
-    PT_HIP(hipEventRecord(ev_init, s->stream));
-    for(Group &gr : G) {
-        PT_HIP(hipStreamWaitEvent(gr.st, ev_init, 0));
-    }
-
-    const bool timing = stats != nullptr;
-    const int kEventPairs = 64; // launches per half of the event ring: a full half is read while the other one fills
-    std::vector<hipEvent_t> ev;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    if(timing) {
-        ev.resize(4 * 2 * kEventPairs);
-        for(auto &e : ev) {
-            PT_HIP(hipEventCreate(&e));
-        }
-        PT_HIP(hipEventCreate(&ev_begin));
-        PT_HIP(hipEventCreate(&ev_end));
-        PT_HIP(hipEventRecord(ev_begin, s->stream));
-    }
-    double trace_ms = 0.0, shade_ms = 0.0;
-    uint64_t launches = 0;
-    std::vector<std::pair<float, float>> trace_intervals; // [start, end) of every traversal launch, ms since ev_begin
-    auto drain_events = [&](int first, int used) -> int {
-        for(int i = first; i < first + used; i++) {
-            float a = 0.0F, b = 0.0F, t0 = 0.0F;
-            PT_HIP(hipEventSynchronize(ev[4 * i + 3]));
-            PT_HIP(hipEventElapsedTime(&a, ev[4 * i + 0], ev[4 * i + 1]));
-            PT_HIP(hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3]));
-            PT_HIP(hipEventElapsedTime(&t0, ev_begin, ev[4 * i + 2]));
-            shade_ms += a;
-            trace_ms += b;
-            trace_intervals.emplace_back(t0, t0 + b);
-        }
-        return PT_OK;
-    };
-
-    const int check_every = n <= 65536 ? 4 : env_int("PT_CHECK_EVERY", 8);
-    uint64_t iterations = 0;
-    int pending = 0;          // next free pair of the event ring
-    bool other_half_used = false; // the half of the ring that `pending` is not in holds unread events
-    uint64_t batch = 0;
-    for(;;) {
-        for(int k = 0; k < check_every; k++) {
-            for(size_t g = 0; g < G.size(); g++) {
-                Group &gr = G[g];
-                if(gr.done) {
-                    continue;
-                }
-                PtDevCounters *cnt = s->counters.ptr + g;
-                if(timing) {
-                    PT_HIP(hipEventRecord(ev[4 * pending + 0], gr.st));
-                }
-                const int parity = static_cast<int>(iterations & 1U);
-                gr.cfg.parity = parity;
-                // this launch's queue header, and the other one for the shading kernel to clear (both were zeroed before the loop)
-                PtQueue q_now = gr.q;
-                q_now.count = gr.q.count + static_cast<size_t>(parity) * 2 * PT_SHARDS * PT_QSTRIDE;
-                q_now.head = q_now.count + PT_SHARDS * PT_QSTRIDE;
-                q_now.next_header = gr.q.count + static_cast<size_t>(parity ^ 1) * 2 * PT_SHARDS * PT_QSTRIDE;
-                pt_launch_shade(gr.st, s->dev, cam, opt, gr.P, q_now, gr.carry, parity, shard_mode, d_image, cnt);
-                if(timing) {
-                    PT_HIP(hipEventRecord(ev[4 * pending + 1], gr.st));
-                    PT_HIP(hipEventRecord(ev[4 * pending + 2], gr.st));
-                }
-                pt_launch_trace(gr.st, s->dev, q_now, gr.carry, gr.P, gr.cfg, cnt);
-                launches++;
-                if(timing) {
-                    PT_HIP(hipEventRecord(ev[4 * pending + 3], gr.st));
-                    pending++;
-                    if(pending == kEventPairs || pending == 2 * kEventPairs) {
-                        // this half is full: read the OTHER half (recorded at least 64 launches ago) and continue into it
-                        const int other = pending == kEventPairs ? kEventPairs : 0;
-                        if(other_half_used) {
-                            int rc = drain_events(other, kEventPairs);
-                            if(rc != PT_OK) {
-                                return rc;
-                            }
-                        }
-                        other_half_used = true;
-                        pending = other;
-                    }
-                }
-            }
-            iterations++;
-        }
-        // The counters of this batch are copied out behind it; the host looks at the copy of the PREVIOUS batch, so the next batch
-        // is queued while the device still works on this one (a finished frame costs one batch of empty launches).
-        bool all_done = true;
-        const size_t slot = static_cast<size_t>(batch & 1U) * PT_MAX_GROUPS, prev_slot = static_cast<size_t>((batch + 1U) & 1U) * PT_MAX_GROUPS;
-        for(size_t g = 0; g < G.size(); g++) {
-            if(!G[g].done) {
-                PT_HIP(hipMemcpyAsync(s->host_counters + slot + g, s->counters.ptr + g, sizeof(PtDevCounters), hipMemcpyDeviceToHost, G[g].st));
-                PT_HIP(hipEventRecord(s->check_event[(batch & 1U) * PT_MAX_GROUPS + g], G[g].st));
-            }
-        }
-        for(size_t g = 0; g < G.size(); g++) {
-            if(!G[g].done) {
-                if(batch == 0) {
-                    all_done = false;
-                    continue;
-                }
-                PT_HIP(hipEventSynchronize(s->check_event[((batch + 1U) & 1U) * PT_MAX_GROUPS + g]));
-                const unsigned long long finished = s->host_counters[prev_slot + g].streams_done;
-                G[g].done = finished >= G[g].count;
-                // Endgame: once most streams have rendered all their pixels the launches are small, and suspending the long walks
-                // of the remaining streams only multiplies the number of (fixed-cost) iterations they need.
-                if(finished * 100ULL >= static_cast<unsigned long long>(G[g].count) * static_cast<unsigned long long>(endgame_percent)) {
-                    G[g].cfg.max_steps = 0x7fffffff;
-                    G[g].cfg.drain_lanes = 0;
-                }
-            }
-            all_done = all_done && G[g].done;
-        }
-        batch++;
-        PT_HIP(hipGetLastError());
-        if(all_done) {
-            break;
-        }
-        if(iterations > (1ULL << 40)) {
-            return fail(PT_ERR_HIP, "wavefront loop did not terminate");
-        }
-    }
-    // the main stream continues after every group
-    for(Group &gr : G) {
-        PT_HIP(hipEventRecord(ev_init, gr.st));
-        PT_HIP(hipStreamWaitEvent(s->stream, ev_init, 0));
-    }
-    (void)hipEventDestroy(ev_init);
-    if(timing) {
-        int rc = PT_OK;
-        if(other_half_used) {
-            rc = drain_events(pending < kEventPairs ? kEventPairs : 0, kEventPairs);
-        }
-        if(rc == PT_OK) {
-            const int first = pending < kEventPairs ? 0 : kEventPairs;
-            rc = drain_events(first, pending - first);
-        }
-        if(rc != PT_OK) {
-            return rc;
-        }
-        PT_HIP(hipEventRecord(ev_end, s->stream));
-        PT_HIP(hipEventSynchronize(ev_end));
-        float total = 0.0F;
-        PT_HIP(hipEventElapsedTime(&total, ev_begin, ev_end));
-        PtDevCounters c{};
-        {
-            std::vector<unsigned long long> shade_slots(s->shade_wave_counters.count), trace_slots(s->trace_wave_counters.count);
-            PT_HIP(hipMemcpy(shade_slots.data(), s->shade_wave_counters.ptr, shade_slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            PT_HIP(hipMemcpy(trace_slots.data(), s->trace_wave_counters.ptr, trace_slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            for(size_t i = 0; i + 1 < shade_slots.size(); i += 2) {
-                c.samples += shade_slots[i];
-                c.vertices += shade_slots[i + 1];
-            }
-            unsigned long long diag[4] = {0, 0, 0, 0};
-            for(size_t i = 0; i + 7 < trace_slots.size(); i += 8) {
-                c.node_visits += trace_slots[i];
-                c.leaf_tests += trace_slots[i + 1];
-                c.rays += trace_slots[i + 2];
-                c.shadow_rays += trace_slots[i + 3];
-                for(int k = 0; k < 4; k++) {
-                    diag[k] += trace_slots[i + 4 + k];
-                }
-            }
-            if(env_int("PT_DEBUG", 0) != 0) {
-                std::fprintf(stderr, "[pt] trace diagnostics: wave steps %llu (%.1f lanes of 64 on an inner node per step), leaf phases %llu (%.1f leaves each), refills %llu, suspended walks %llu\n",
-                             diag[0], diag[0] ? static_cast<double>(c.node_visits) / static_cast<double>(diag[0]) : 0.0, diag[1],
-                             diag[1] ? static_cast<double>(c.leaf_tests) / static_cast<double>(diag[1]) : 0.0, diag[2], diag[3]);
-            }
-        }
-        stats->samples = c.samples;
-        stats->rays_traced = c.rays;
-        stats->shadow_rays_traced = c.shadow_rays;
-        stats->node_visits = c.node_visits;
-        stats->leaf_tests = c.leaf_tests;
-        stats->vertices = c.vertices;
-        stats->iterations = launches;
-        stats->trace_ms = trace_ms;
-        {
-            // union of the traversal launches' intervals (the groups' launches overlap)
-            std::sort(trace_intervals.begin(), trace_intervals.end());
-            double busy = 0.0;
-            float open_from = 0.0F, open_to = -1.0F;
-            for(const auto &iv : trace_intervals) {
-                if(iv.first > open_to) {
-                    busy += open_to > open_from ? static_cast<double>(open_to - open_from) : 0.0;
-                    open_from = iv.first;
-                    open_to = iv.second;
-                }
-                else {
-                    open_to = std::max(open_to, iv.second);
-                }
-            }
-            busy += open_to > open_from ? static_cast<double>(open_to - open_from) : 0.0;
-            stats->trace_busy_ms = busy;
-            stats->groups = G.size();
-        }
-        stats->shade_ms = shade_ms;
-        stats->total_ms = total;
-        for(auto &e : ev) {
-            (void)hipEventDestroy(e);
-        }
-        (void)hipEventDestroy(ev_begin);
-        (void)hipEventDestroy(ev_end);
     }
     return PT_OK;
 }
@@ -883,7 +339,7 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     PT_HIP(s->path_wave_counters.ensure(static_cast<size_t>(waves) * 8U));
     PT_HIP(s->walk_save.ensure(static_cast<size_t>(waves) * 64U * PT_WALK_SAVE_WORDS));
     PT_HIP(s->pull_counter.ensure(64));
-    PT_HIP(s->counters.ensure(PT_MAX_GROUPS));
+    PT_HIP(s->counters.ensure(1));
     cfg.spill = s->path_spill.ptr;
     cfg.walk_save = s->walk_save.ptr;
     cfg.wave_counters = s->path_wave_counters.ptr;
@@ -992,38 +448,18 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
         stats->shadow_rays_traced = sum[3];
         stats->samples = sum[6];
         stats->vertices = sum[7];
-        stats->iterations = 1;
-        stats->trace_ms = ms;
-        stats->trace_busy_ms = ms;
-        stats->shade_ms = 0.0;
-        stats->total_ms = ms;
-        stats->groups = 1;
+        stats->launches = 1;
+        stats->kernel_ms = ms;
+        stats->wave_steps = sum[4];
+        stats->shading_passes = sum[5];
+        stats->wavefronts = s->path_waves;
+        stats->slot_rows = static_cast<uint64_t>(cfg.rows);
         if(env_int("PT_DEBUG", 0) != 0) {
             std::fprintf(stderr, "[pt] path kernel: %.2f ms, grid %d x 256, %d rows; wave steps %llu (%.1f lanes of 64 busy per step), shading passes %llu, rays %llu\n", ms, cfg.grid,
                          cfg.rows, sum[4], sum[4] ? static_cast<double>(sum[0] + sum[1]) / static_cast<double>(sum[4]) : 0.0, sum[5], sum[2]);
         }
     }
     return PT_OK;
-}
-
-uint32_t choose_groups(pt_scene *s, uint32_t n) {
-    // Measured: three groups of streams on three HIP streams, so that one group's shading (and the thin end of its
-    // traversal launches) overlaps the others' traversal.  Scenes that live in LDS: +23 % (two groups +13 %, four -3 %).  HBM-resident
-    // trees: +12 %, provided every group's persistent traversal grid is limited to two workgroups per CU (run_wavefront) -- with
-    // full-size grids the kernels of the groups only queue up behind each other (-4 %).
-    const int by_scene = 3;
-    const int want = std::min(std::max(env_int("PT_GROUPS", by_scene), 1), PT_MAX_GROUPS);
-    // a group should still fill the chip's lanes on its own now and then: at least 128 K streams per group
-    const uint32_t by_size = std::max<uint32_t>(1U, n / 131072U);
-    uint32_t groups = std::min<uint32_t>(static_cast<uint32_t>(want), by_size);
-    if(groups > 1) {
-        // no more groups than streams that really run side by side (groups sharing a stream would only queue up)
-        if(s->group_stream[groups - 1] == nullptr && pick_concurrent_streams(s, groups) != PT_OK) {
-            return 1;
-        }
-        groups = std::max<uint32_t>(1U, std::min<uint32_t>(groups, s->concurrent_streams));
-    }
-    return groups;
 }
 
 } // namespace
@@ -1039,7 +475,11 @@ const char *pt_last_error(void) {
 }
 
 uint64_t pt_pixel_seed(uint64_t base_seed, int32_t x, int32_t y) {
-    return pt_host_pixel_seed(base_seed, x, y);
+    // splitmix64 finaliser over (base_seed, x, y); the device computes the same (pt_shading.h pixel_seed)
+    uint64_t z = base_seed + 0x9E3779B97F4A7C15ULL * (1ULL + (static_cast<uint64_t>(static_cast<uint32_t>(y)) << 32) + static_cast<uint64_t>(static_cast<uint32_t>(x)));
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
 }
 
 uint64_t pt_rng_seed_to_state(uint64_t seed) {
@@ -1158,7 +598,6 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
 
     std::vector<int32_t> dfs; // leaves depth-first, left to right (Scene::registerEmissiveObjects order); device path: only those with an emissive material
     uint32_t n_pairs = 0, root_ref = PT_REF_NONE;
-    std::vector<uint32_t> level_begin; // pair slots of the tree's levels (for the two-level records)
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
     if(use_device) {
         // ---- device: upload the caller's arrays as they are; records, leaf boxes and the tree are made in HBM ----------------------
@@ -1225,7 +664,6 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         }
         n_pairs = built.n_pairs;
         root_ref = built.root_ref;
-        level_begin = built.level_begin;
         for(int k = 0; k < 3; k++) {
             root_lo[k] = built.root_lo[k];
             root_hi[k] = built.root_hi[k];
@@ -1294,7 +732,6 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         ptb::FlatBvh flat = ptb::flatten_breadth_first(s->tree, leaf_ref, align_siblings);
         n_pairs = flat.n_pairs;
         root_ref = flat.root_ref;
-        level_begin = flat.level_begin;
         for(int k = 0; k < 3; k++) {
             root_lo[k] = flat.root_box.lo[k];
             root_hi[k] = flat.root_box.hi[k];
@@ -1459,38 +896,21 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     dev.n_lights = d->n_point_lights;
     dev.n_emis = s->n_emissive;
     dev.n_object_samples = static_cast<uint32_t>(object_sample_count);
-    // LDS staging: a scene whose whole tree and triangle records fit in 24 KiB lives in LDS entirely; for larger scenes the
-    // traversal kernel is bound by instruction issue, not by node latency, and an LDS copy of the top of the tree only costs
-    // occupancy (measured: profiles/), so it is off unless PT_LDS_PAIRS asks for it.
+    // LDS staging: a scene whose whole tree and triangle records fit in 24 KiB lives in LDS entirely (the path kernel's IN_LDS
+    // variant); an LDS copy of only the top of a larger tree was measured in round 1 and does not pay.
     const size_t small_bytes = static_cast<size_t>(n_pairs) * 64 + static_cast<size_t>(d->n_triangles) * 48;
     if(small_bytes <= 24 * 1024 && env_int("PT_LDS_SMALL", 1) != 0) {
         dev.n_lds_pairs = n_pairs;
         dev.n_lds_tris = d->n_triangles;
     }
     else {
-        dev.n_lds_pairs = std::min(n_pairs, static_cast<uint32_t>(std::max(env_int("PT_LDS_PAIRS", 0), 0)));
+        dev.n_lds_pairs = 0;
         dev.n_lds_tris = 0;
     }
 
-    dev.quads = nullptr;
-    dev.n_quads = 0;
-    if(dev.n_lds_pairs == 0 && n_pairs > 0 && (root_ref & PT_REF_LEAF) == 0 && env_int("PT_WIDE", 0) != 0) {
-        // HBM-resident tree: two-level records, one dependent fetch per two levels of a walk (pt_trace.hip, LDS_MODE 3)
-        float4 *quads = nullptr;
-        uint32_t n_quads = 0;
-        PT_HIP(pt_build_quads(s->stream, reinterpret_cast<const float4 *>(s->pairs.ptr), level_begin, &quads, &n_quads));
-        s->quads.ptr = reinterpret_cast<F4 *>(quads);
-        s->quads.count = 12 * static_cast<size_t>(n_quads);
-        dev.quads = quads;
-        dev.n_quads = n_quads;
-    }
-
-    int rc = setup_trace(s.get());
+    int rc = setup_path(s.get());
     if(rc != PT_OK) {
         return rc;
-    }
-    if(const char *kernel = std::getenv("PT_KERNEL")) {
-        s->use_path = std::strcmp(kernel, "wavefront") != 0; // A/B against round 1's two-kernel wavefront loop
     }
     s->build_ms[3] = ms_since(t_rest);
     if(env_int("PT_DEBUG", 0) != 0) {
@@ -1508,16 +928,6 @@ void pt_scene_destroy(pt_scene *scene) {
     (void)hipSetDevice(scene->device);
     if(scene->stream != nullptr) {
         (void)hipStreamSynchronize(scene->stream);
-    }
-    if(scene->walk_hist.ptr != nullptr) {
-        uint32_t h[64];
-        if(hipMemcpy(h, scene->walk_hist.ptr, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            std::fprintf(stderr, "[pt] inner-node steps per walk (bucket b: 2^(b-1) <= steps < 2^b):");
-            for(int b = 0; b < 16; b++) {
-                std::fprintf(stderr, " %u", h[b]);
-            }
-            std::fprintf(stderr, "\n");
-        }
     }
     delete scene;
 }
@@ -1630,7 +1040,7 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
     std::lock_guard<std::mutex> lock(s->render_mutex);
     PT_HIP(hipSetDevice(s->device));
     const uint32_t n32 = static_cast<uint32_t>(n);
-    if(s->use_path) {
+    {
         int rc = setup_path(s);
         if(rc != PT_OK) {
             return rc;
@@ -1655,51 +1065,6 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
         }
         return PT_OK;
     }
-    int rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples);
-    if(rc != PT_OK) {
-        return rc;
-    }
-    PT_HIP(s->batch_rays.ensure(6 * n));
-    PtPaths P = make_paths(s, n32);
-    PtQueue q = make_queue(s);
-    if(q.shard_capacity < (n32 + PT_SHARDS - 1) / PT_SHARDS) {
-        return fail(PT_ERR_NOMEM, "queue too small for batch");
-    }
-    hipStream_t st = s->stream;
-    PT_HIP(hipMemcpyAsync(s->batch_rays.ptr, rays, 6 * n * sizeof(float), hipMemcpyHostToDevice, st));
-    PT_HIP(hipMemsetAsync(s->q_header.ptr, 0, 2 * PT_SHARDS * PT_QSTRIDE * sizeof(uint32_t), st));
-    PT_HIP(hipMemsetAsync(s->counters.ptr, 0, sizeof(PtDevCounters), st));
-    pt_launch_batch_rays(st, s->batch_rays.ptr, n32, q);
-    PtTraceConfig trace_cfg = s->trace_cfg;
-    trace_cfg.spill = s->spill.ptr;
-    trace_cfg.grid = static_cast<int>(std::max<uint32_t>(1U, std::min<uint32_t>(static_cast<uint32_t>(trace_cfg.grid), (n32 + 255U) / 256U)));
-    trace_cfg.max_steps = 0x7fffffff;
-    trace_cfg.drain_lanes = 0;
-    trace_cfg.parity = 0;
-    trace_cfg.wave_counters = s->trace_wave_counters.ptr;
-    PT_HIP(hipMemsetAsync(s->carry_header.ptr, 0, 4 * PT_QSTRIDE * sizeof(uint32_t), st));
-    PtCarry carry = make_carry(s, 0);
-    carry.cap = 0;
-    pt_launch_trace(st, s->dev, q, carry, P, trace_cfg, s->counters.ptr);
-    std::vector<uint2> hits(n);
-    PT_HIP(hipMemcpyAsync(hits.data(), s->hit.ptr, n * sizeof(uint2), hipMemcpyDeviceToHost, st));
-    PT_HIP(hipStreamSynchronize(st));
-    PT_HIP(hipGetLastError());
-    for(size_t i = 0; i < n; i++) {
-        const float t = from_bits(hits[i].x);
-        const uint32_t ref = hits[i].y;
-        out_t[i] = t;
-        if(t < 0.0F || ref == PT_REF_NONE) {
-            out_obj[i] = -1;
-        }
-        else if(ref & PT_REF_SPHERE) {
-            out_obj[i] = static_cast<int32_t>(s->sph_obj[ref & PT_REF_INDEX]);
-        }
-        else {
-            out_obj[i] = static_cast<int32_t>(s->tri_obj[ref & PT_REF_INDEX]);
-        }
-    }
-    return PT_OK;
 }
 
 int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_stream *streams, size_t n, float *out_image,
@@ -1742,7 +1107,7 @@ int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_opti
     const size_t pixels = static_cast<size_t>(options->image_width) * static_cast<size_t>(options->image_height);
     PT_HIP(s->image.ensure(pixels));
     hipStream_t st = s->stream;
-    if(s->use_path) {
+    {
         PT_HIP(s->st_rect.ensure(n));
         PT_HIP(s->st_rng.ensure(n));
         // pixels not covered by a stream keep the caller's values
@@ -1765,26 +1130,6 @@ int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_opti
         PT_HIP(hipStreamSynchronize(st));
         return PT_OK;
     }
-    const uint32_t groups = choose_groups(s, n32);
-    rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples, groups);
-    if(rc != PT_OK) {
-        return rc;
-    }
-    // pixels not covered by a stream keep the caller's values
-    PT_HIP(hipMemcpyAsync(s->image.ptr, out_image, pixels * sizeof(F4), hipMemcpyHostToDevice, st));
-    PT_HIP(hipMemcpyAsync(s->rect.ptr, rects.data(), n * sizeof(int4), hipMemcpyHostToDevice, st));
-    PT_HIP(hipMemcpyAsync(s->rng.ptr, states.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    pt_launch_init_streams(st, make_paths(s, n32));
-    rc = run_wavefront(s, cam, opt, n32, groups, reinterpret_cast<float4 *>(s->image.ptr), stats);
-    if(rc != PT_OK) {
-        return rc;
-    }
-    PT_HIP(hipMemcpyAsync(out_image, s->image.ptr, pixels * sizeof(F4), hipMemcpyDeviceToHost, st));
-    if(out_states != nullptr) {
-        PT_HIP(hipMemcpyAsync(out_states, s->rng.ptr, n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    }
-    PT_HIP(hipStreamSynchronize(st));
-    return PT_OK;
 }
 
 static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles, uint64_t base_seed,
@@ -1807,7 +1152,7 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
         return fail(PT_ERR_INVALID, "too many pixels in one call");
     }
     const uint32_t n32 = static_cast<uint32_t>(total);
-    if(s->use_path) {
+    {
         // stream i = pixel i of the tiles laid end to end; the kernel derives rectangle and engine from the tile table
         std::vector<int4> rects(n_tiles);
         std::vector<uint32_t> offsets(n_tiles), left(n_tiles);
@@ -1837,34 +1182,6 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
         T.base_seed = base_seed;
         return run_path(s, cam, opt, T, d_image, stats, progress, progress_user);
     }
-    const uint32_t groups = choose_groups(s, n32);
-    // Stream slots are laid out tile after tile and the stream groups are contiguous ranges of slots: with the tiles in the caller's
-    // (row-major) order a group is a horizontal band of the frame.  That is deliberate: the bands differ in cost, so the groups reach
-    // the thin end of their work at different times and one group's tail overlaps the others' full launches (dealing the tiles out
-    // to the groups in turn was measured: -2 %).
-    std::vector<int4> rects(n_tiles);
-    std::vector<uint32_t> offsets(n_tiles);
-    {
-        uint64_t at = 0;
-        for(size_t k = 0; k < n_tiles; k++) {
-            const pt_tile &t = tiles[k];
-            rects[k] = make_int4(t.x, t.y, t.w, t.h);
-            offsets[k] = static_cast<uint32_t>(at);
-            at += static_cast<uint64_t>(t.w) * static_cast<uint64_t>(t.h);
-        }
-    }
-    rc = ensure_workspace(s, n32, 1U + s->dev.n_lights + s->dev.n_object_samples, groups);
-    if(rc != PT_OK) {
-        return rc;
-    }
-    PT_HIP(s->tiles.ensure(n_tiles));
-    PT_HIP(s->tile_offset.ensure(n_tiles));
-    hipStream_t st = s->stream;
-    PT_HIP(hipMemcpyAsync(s->tiles.ptr, rects.data(), n_tiles * sizeof(int4), hipMemcpyHostToDevice, st));
-    PT_HIP(hipMemcpyAsync(s->tile_offset.ptr, offsets.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    pt_launch_init_tiles(st, make_paths(s, n32), s->tiles.ptr, s->tile_offset.ptr, static_cast<uint32_t>(n_tiles), base_seed);
-    PT_HIP(hipStreamSynchronize(st)); // rects/offsets are stack-owned host vectors
-    return run_wavefront(s, cam, opt, n32, groups, d_image, stats);
 }
 
 int pt_render_tiles(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles, uint64_t base_seed,
@@ -1898,6 +1215,165 @@ int pt_render_tiles_progress(pt_scene *s, const pt_camera_params *camera, const 
     }
     PT_HIP(hipMemcpyAsync(out_image, s->image.ptr, pixels * sizeof(F4), hipMemcpyDeviceToHost, s->stream));
     PT_HIP(hipStreamSynchronize(s->stream));
+    return PT_OK;
+}
+
+int pt_render_item(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_stream *item, float *out_tile, uint64_t *out_state,
+                   pt_stats *stats) {
+    int rc = check_render_args(s, camera, options);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    if(item == nullptr) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    if(stats != nullptr) {
+        std::memset(stats, 0, sizeof(*stats));
+    }
+    if(item->w < 0 || item->h < 0 || item->x < 0 || item->y < 0 || item->x + item->w > options->image_width || item->y + item->h > options->image_height) {
+        return fail(PT_ERR_INVALID, "work item outside the image");
+    }
+    if(out_state != nullptr) {
+        *out_state = item->rng_state;
+    }
+    if(item->w == 0 || item->h == 0) {
+        return PT_OK; // a zero-area WorkItem renders nothing and leaves its engine untouched
+    }
+    if(out_tile == nullptr) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    PtDevOptions opt;
+    rc = derive_options(options, &opt);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    const PtDevCamera cam = derive_camera(camera);
+    std::lock_guard<std::mutex> lock(s->render_mutex);
+    PT_HIP(hipSetDevice(s->device));
+    // the frame exists in device memory only; the host sees the item's rectangle
+    const size_t pixels = static_cast<size_t>(options->image_width) * static_cast<size_t>(options->image_height);
+    PT_HIP(s->image.ensure(pixels));
+    PT_HIP(s->st_rect.ensure(1));
+    PT_HIP(s->st_rng.ensure(1));
+    hipStream_t st = s->stream;
+    const int4 rect = make_int4(item->x, item->y, item->w, item->h);
+    PT_HIP(hipMemcpyAsync(s->st_rect.ptr, &rect, sizeof(rect), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(s->st_rng.ptr, &item->rng_state, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    PT_HIP(hipStreamSynchronize(st));
+    PtStreams T{};
+    T.n = 1;
+    T.rect = s->st_rect.ptr;
+    T.rng = s->st_rng.ptr;
+    rc = run_path(s, cam, opt, T, reinterpret_cast<float4 *>(s->image.ptr), stats, nullptr, nullptr);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    const F4 *first = s->image.ptr + static_cast<size_t>(item->y) * static_cast<size_t>(options->image_width) + static_cast<size_t>(item->x);
+    PT_HIP(hipMemcpy2DAsync(out_tile, static_cast<size_t>(item->w) * sizeof(F4), first, static_cast<size_t>(options->image_width) * sizeof(F4),
+                            static_cast<size_t>(item->w) * sizeof(F4), static_cast<size_t>(item->h), hipMemcpyDeviceToHost, st));
+    if(out_state != nullptr) {
+        PT_HIP(hipMemcpyAsync(out_state, s->st_rng.ptr, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    }
+    PT_HIP(hipStreamSynchronize(st));
+    return PT_OK;
+}
+
+int pt_render_tiles_multi(pt_scene *const *scenes, int n_scenes, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles,
+                          uint64_t base_seed, float *out_image, pt_stats *stats, pt_progress_fn progress, void *progress_user) {
+    if(scenes == nullptr || n_scenes < 1) {
+        return fail(PT_ERR_INVALID, "no scenes");
+    }
+    for(int i = 0; i < n_scenes; i++) {
+        const int rc = check_render_args(scenes[i], camera, options);
+        if(rc != PT_OK) {
+            return rc;
+        }
+    }
+    if(n_tiles == 0) {
+        return PT_OK;
+    }
+    if(tiles == nullptr || out_image == nullptr) {
+        return fail(PT_ERR_INVALID, "null argument");
+    }
+    for(size_t k = 0; k < n_tiles; k++) {
+        const pt_tile &t = tiles[k];
+        if(t.w <= 0 || t.h <= 0 || t.x < 0 || t.y < 0 || t.x + t.w > options->image_width || t.y + t.h > options->image_height) {
+            return fail(PT_ERR_INVALID, "tile outside the image or empty");
+        }
+    }
+    // The multi-device form of doWorkParallel (src/worker.cpp:364-387): tile k goes to scene k % n_scenes (each scene a replica on its
+    // own device), one host thread per scene drives its device, every device renders into its own frame in HBM, and the frames meet in the
+    // caller's image (one device-to-host copy per device, then the rows of that device's tiles).  Engines are per pixel, so the image
+    // does not depend on n_scenes.  progress calls are serialised and counted over all devices.
+    struct Shared {
+        std::mutex progress_mutex;
+        int completed = 0, total = 0;
+        pt_progress_fn fn = nullptr;
+        void *user = nullptr;
+    } shared;
+    shared.total = static_cast<int>(n_tiles);
+    shared.fn = progress;
+    shared.user = progress_user;
+    auto trampoline = [](int, int, void *p) {
+        Shared *sh = static_cast<Shared *>(p);
+        std::lock_guard<std::mutex> lock(sh->progress_mutex);
+        sh->completed++;
+        sh->fn(sh->completed, sh->total, sh->user);
+    };
+    std::vector<int> rcs(static_cast<size_t>(n_scenes), PT_OK);
+    std::vector<std::string> errors(static_cast<size_t>(n_scenes));
+    const size_t width = static_cast<size_t>(options->image_width), pixels = width * static_cast<size_t>(options->image_height);
+    auto work = [&](int i) {
+        std::vector<pt_tile> mine;
+        for(size_t k = static_cast<size_t>(i); k < n_tiles; k += static_cast<size_t>(n_scenes)) {
+            mine.push_back(tiles[k]);
+        }
+        if(mine.empty()) {
+            return;
+        }
+        pt_scene *s = scenes[i];
+        std::vector<float> frame(pixels * 4);
+        auto run = [&]() -> int {
+            std::lock_guard<std::mutex> lock(s->render_mutex);
+            PT_HIP(hipSetDevice(s->device));
+            PT_HIP(s->image.ensure(pixels));
+            int rc = render_tiles_impl(s, camera, options, mine.data(), mine.size(), base_seed, reinterpret_cast<float4 *>(s->image.ptr),
+                                       stats != nullptr ? stats + i : nullptr, progress != nullptr ? static_cast<pt_progress_fn>(trampoline) : nullptr, &shared);
+            if(rc != PT_OK) {
+                return rc;
+            }
+            PT_HIP(hipMemcpyAsync(frame.data(), s->image.ptr, pixels * sizeof(F4), hipMemcpyDeviceToHost, s->stream));
+            PT_HIP(hipStreamSynchronize(s->stream));
+            return PT_OK;
+        };
+        rcs[static_cast<size_t>(i)] = run();
+        if(rcs[static_cast<size_t>(i)] != PT_OK) {
+            errors[static_cast<size_t>(i)] = g_last_error; // this thread's message
+            return;
+        }
+        for(const pt_tile &t : mine) {
+            for(int y = t.y; y < t.y + t.h; y++) {
+                const size_t at = (static_cast<size_t>(y) * width + static_cast<size_t>(t.x)) * 4;
+                std::memcpy(out_image + at, frame.data() + at, static_cast<size_t>(t.w) * 4 * sizeof(float));
+            }
+        }
+    };
+    if(stats != nullptr) {
+        std::memset(stats, 0, sizeof(*stats) * static_cast<size_t>(n_scenes));
+    }
+    std::vector<std::thread> threads;
+    for(int i = 1; i < n_scenes; i++) {
+        threads.emplace_back(work, i);
+    }
+    work(0);
+    for(std::thread &t : threads) {
+        t.join();
+    }
+    for(int i = 0; i < n_scenes; i++) {
+        if(rcs[static_cast<size_t>(i)] != PT_OK) {
+            return fail(rcs[static_cast<size_t>(i)], "scene " + std::to_string(i) + ": " + errors[static_cast<size_t>(i)]);
+        }
+    }
     return PT_OK;
 }
 

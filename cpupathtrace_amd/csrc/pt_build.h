@@ -45,10 +45,6 @@ struct PtBuildOutput {
 // Requires n_objects >= 2.
 hipError_t pt_build_scene_device(hipStream_t stream, const PtBuildInput &in, PtBuildOutput &out, const char **error_text);
 
-// Two-level records for the traversal of HBM-resident trees (pt_types.h: quads): for every inner node of an EVEN level a 192-byte
-// record = its own pair record followed by the pair records of its two children (zeros where a child is a leaf), with the
-// grandchildren's references rewritten to record indices.  `quads_out` is hipMalloc'ed; ownership passes to the caller.
-hipError_t pt_build_quads(hipStream_t stream, const float4 *pairs, const std::vector<uint32_t> &level_begin, float4 **quads_out, uint32_t *n_quads_out);
 
 // Positions of the objects whose bit is set in `mask_bits` (host array, one bit per object) within the depth-first leaf order
 // `dfs` (device).  On return `ordered` lists those objects in depth-first order.

@@ -626,48 +626,6 @@ __global__ void k_select(uint32_t n, const uint32_t *__restrict__ dfs, const uin
     }
 }
 
-// one 192-byte record per inner node of an even level: [own pair record | left child's | right child's]
-__global__ void k_make_quads(uint32_t begin, uint32_t end, uint32_t base, uint32_t grand_begin, uint32_t grand_base, const float *__restrict__ pairs,
-                             float *__restrict__ quads) {
-    const uint32_t slot = begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if(slot >= end) {
-        return;
-    }
-    const float *q = pairs + 16 * static_cast<size_t>(slot);
-    float *out = quads + 48 * static_cast<size_t>(base + (slot - begin));
-    const uint32_t refs[2] = {__float_as_uint(q[12]), __float_as_uint(q[13])};
-    if(refs[0] == 0u && refs[1] == 0u) {
-        for(int k = 0; k < 48; k++) {
-            out[k] = 0.0f; // alignment slot of the pair array
-        }
-        return;
-    }
-    for(int k = 0; k < 16; k++) {
-        out[k] = q[k];
-    }
-    for(int c = 0; c < 2; c++) {
-        float *dst = out + 16 + 16 * c;
-        if(refs[c] & PT_REF_LEAF) {
-            for(int k = 0; k < 16; k++) {
-                dst[k] = 0.0f;
-            }
-            continue;
-        }
-        const float *cq = pairs + 16 * static_cast<size_t>(refs[c]);
-        for(int k = 0; k < 12; k++) {
-            dst[k] = cq[k];
-        }
-        for(int k = 0; k < 2; k++) {
-            uint32_t g = __float_as_uint(cq[12 + k]);
-            if(!(g & PT_REF_LEAF)) {
-                g = grand_base + (g - grand_begin); // an inner grandchild: the index of ITS record
-            }
-            dst[12 + k] = __uint_as_float(g);
-        }
-        dst[14] = 0.0f;
-        dst[15] = 0.0f;
-    }
-}
 
 struct Scratch {
     std::vector<void *> ptrs;
@@ -939,39 +897,3 @@ hipError_t pt_build_order_subset(hipStream_t stream, const uint32_t *dfs, uint32
     return hipSuccess;
 }
 
-hipError_t pt_build_quads(hipStream_t stream, const float4 *pairs, const std::vector<uint32_t> &level_begin, float4 **quads_out, uint32_t *n_quads_out) {
-    *quads_out = nullptr;
-    *n_quads_out = 0;
-    const size_t levels = level_begin.size() > 0 ? level_begin.size() - 1 : 0;
-    if(levels == 0) {
-        return hipSuccess;
-    }
-    std::vector<uint32_t> base(levels + 2, 0);
-    uint32_t total = 0;
-    for(size_t l = 0; l < levels; l += 2) {
-        base[l] = total;
-        total += level_begin[l + 1] - level_begin[l];
-    }
-    float *quads = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&quads), static_cast<size_t>(total) * 192);
-    if(e != hipSuccess) {
-        return e;
-    }
-    for(size_t l = 0; l < levels; l += 2) {
-        const uint32_t begin = level_begin[l], end = level_begin[l + 1];
-        const bool has_grand = l + 2 < levels;
-        hipLaunchKernelGGL(k_make_quads, grid_for(end - begin), dim3(256), 0, stream, begin, end, base[l], has_grand ? level_begin[l + 2] : 0u, has_grand ? base[l + 2] : 0u,
-                           reinterpret_cast<const float *>(pairs), quads);
-    }
-    e = hipGetLastError();
-    if(e == hipSuccess) {
-        e = hipStreamSynchronize(stream);
-    }
-    if(e != hipSuccess) {
-        (void)hipFree(quads);
-        return e;
-    }
-    *quads_out = reinterpret_cast<float4 *>(quads);
-    *n_quads_out = total;
-    return hipSuccess;
-}

@@ -3,16 +3,12 @@
 // HBM layout of a scene (all arrays 16-byte aligned, indices 32-bit):
 //   pairs     float4[4 * n_pairs]   one 64-byte record per INNER node of the reference's BVH: the boxes of its two children
 //                                   and a 32-bit reference for each child.  Records are in breadth-first order, so the top
-//                                   of the tree has the lowest indices (it is what the traversal kernel stages in LDS).
+//                                   of the tree has the lowest indices.
 //                                     q0 = (L.lo.x, L.lo.y, L.lo.z, L.hi.x)
 //                                     q1 = (L.hi.y, L.hi.z, R.lo.x, R.lo.y)
 //                                     q2 = (R.lo.z, R.hi.x, R.hi.y, R.hi.z)
 //                                     q3 = (bits L.ref, bits R.ref, 0, 0)
-//   quads     float4[12 * n_quads]  (scenes whose tree does not fit in LDS) one 192-byte record per inner node of an EVEN level:
-//                                   its own pair record, then the pair records of its left and right child (zeros for a leaf
-//                                   child); references to inner grandchildren are indices into this array.  One fetch serves
-//                                   two levels of the walk.
-//   tris      float4[3 * n_tris]    48-byte record per triangle for Moeller-Trumbore and the barycentric normal:
+//   tris      float4[3 * n_tris + 1] 48-byte record per triangle (+ one padding word: a traversal step reads 64 bytes) for Moeller-Trumbore and the barycentric normal:
 //                                     q0 = (a.x, a.y, a.z, ab.x)  q1 = (ab.y, ab.z, ac.x, ac.y)  q2 = (ac.z, bits material, bits (obj | cull << 31), 0)
 //                                   ab = b - a and ac = c - a are the fp32 differences the reference forms on every call
 //                                   (src/scene/object.cpp:127-128,149-150), formed once on the host.
@@ -37,8 +33,6 @@
 #define PT_REF_SPHERE 0x40000000u
 #define PT_REF_INDEX 0x3fffffffu
 #define PT_REF_NONE 0xffffffffu /* also: a leaf holding the NullObject of an empty scene */
-#define PT_REF_PENDING 0xfffffffeu /* in a hit record: the extension ray has not finished its walk yet */
-#define PT_VIS_PENDING 2u          /* in a visibility word: the shadow ray has not finished its walk yet */
 
 #define PT_MAX_NEE 8        /* light samples per path vertex: point lights + object samples */
 #define PT_MAX_CANDIDATES 8 /* closed candidates of the per-pixel estimator (worker.cpp:183-185) */
@@ -63,10 +57,8 @@ struct PtDevScene {
     uint32_t n_lights;
     uint32_t n_emis;
     uint32_t n_object_samples; /* min(2 + int(log10(E + 1)), E), scene.cpp:226 */
-    uint32_t n_lds_pairs;      /* pair records staged in LDS by the traversal kernel */
-    uint32_t n_lds_tris;       /* triangle records staged in LDS */
-    const float4 *quads;       /* two-level records (12 float4 each) for HBM-resident trees, or null: see pt_trace.hip */
-    uint32_t n_quads;
+    uint32_t n_lds_pairs;      /* small scenes: all pair records are staged in LDS by the path kernel (else 0) */
+    uint32_t n_lds_tris;       /* small scenes: all triangle records are staged in LDS (else 0) */
 };
 
 // Derived camera state, Camera::Camera (src/camera.cpp:53-76)
@@ -130,13 +122,6 @@ struct PtDevCounters {
     unsigned long long vertices;
     unsigned long long streams_done;
     unsigned long long pad;
-};
-
-// Ray queue header written by the shading kernel and consumed by the traversal kernel.
-struct PtQueueHeader {
-    uint32_t count;    /* rays appended this iteration */
-    uint32_t head[8];  /* per-XCD dequeue heads, relative to the segment start */
-    uint32_t pad[7];
 };
 
 #endif

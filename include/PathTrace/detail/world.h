@@ -257,7 +257,9 @@ struct pt_scene;
 
 class Scene {
   public:
-    // takes ownership; builds the hierarchy and the device-resident copy (device = $PATHTRACE_DEVICE, default 0)
+    // takes ownership; builds the hierarchy and the device-resident copy (device = $PATHTRACE_DEVICE, default 0).  With
+    // $PATHTRACE_DEVICES = N (or "all") the scene is replicated on N devices starting at that one and processJob deals its tiles
+    // out to them (src/worker.cpp:364-387's worker threads become one persistent launch per device).
     Scene(std::vector<std::unique_ptr<Object>> &&objects, std::vector<std::unique_ptr<LightSource>> &&light_sources);
     ~Scene();
     Scene(const Scene &) = delete;
@@ -271,13 +273,15 @@ class Scene {
 
     // the device scene behind the C ABI (include/pt_hip.h); used by processJob / processItem
     pt_scene *deviceScene() const noexcept { return device_scene; }
+    const std::vector<pt_scene *> &deviceScenes() const noexcept { return replicas; }
 
   private:
     std::vector<std::unique_ptr<Object>> objects;
     std::vector<std::unique_ptr<LightSource>> light_sources;
     std::vector<const Object *> emissive;      // in registration order
     std::vector<float> emissive_cdf;           // normalised inclusive prefix sums
-    pt_scene *device_scene = nullptr;
+    pt_scene *device_scene = nullptr;     // = replicas[0]
+    std::vector<pt_scene *> replicas;     // one per device
 };
 
 #endif

@@ -100,20 +100,21 @@ typedef struct pt_stream {
     uint64_t rng_state;
 } pt_stream;
 
-/* Work done by one render call, measured on the device (counts) and with HIP events on the library's stream (times). */
+/* Work done by one render call, counted on the device by the kernel itself; the time is measured with HIP events around the launch
+ * on the library's stream. */
 typedef struct pt_stats {
     uint64_t samples;           /* getSample calls (worker.cpp:194) */
-    uint64_t rays_traced;       /* closest-hit + shadow rays handed to the traversal kernel */
+    uint64_t rays_traced;       /* closest-hit + shadow rays walked through the tree */
     uint64_t shadow_rays_traced;
     uint64_t node_visits;       /* inner nodes visited = pairs of AABB slab tests */
     uint64_t leaf_tests;        /* Triangle/Sphere::getIntersection calls */
     uint64_t vertices;          /* path vertices shaded */
-    uint64_t iterations;        /* wavefront iterations (one shade + one trace launch each) */
-    double trace_ms;            /* summed duration of the traversal kernel launches */
-    double shade_ms;            /* summed duration of the shading kernel launches */
-    double total_ms;            /* first launch to last completion */
-    double trace_busy_ms;       /* time during which at least one traversal launch was running (groups of streams run concurrently) */
-    uint64_t groups;            /* stream groups the job was split into */
+    uint64_t launches;          /* launches of the path kernel (one per render call) */
+    double kernel_ms;           /* duration of the launch */
+    uint64_t wave_steps;        /* traversal steps executed by wavefronts (each serves up to 64 walks) */
+    uint64_t shading_passes;    /* shading passes executed by wavefronts */
+    uint64_t wavefronts;        /* wavefronts of the launch */
+    uint64_t slot_rows;         /* rows of 64 stream slots per wavefront */
 } pt_stats;
 
 typedef struct pt_scene pt_scene;
@@ -126,7 +127,10 @@ const char *pt_last_error(void);
 /* Scene::Scene (src/scene/scene.cpp:153-181): builds the reference's BVH topology (impl::constructBVH, scene.cpp:12-102) on
  * the host, registers emissive objects (scene.cpp:183-208), flattens everything into device arrays on `device`.
  * PT_ERR_UNSUPPORTED: more than 8 light samples per path vertex (point lights + min(2 + log10(E + 1), E) object samples),
- * or a BVH deeper than 128 levels. */
+ * or a BVH deeper than 128 levels.
+ * Thread safety: calls on DIFFERENT scenes may run concurrently; render and intersection calls on the SAME scene are serialised inside
+ * the library (one workspace per scene), so callers that run processItem from several threads on one Scene -- as the reference's
+ * doWork does (src/worker.cpp:328-362) -- are correct, they just do not overlap on the device. */
 int pt_scene_create(int device, const pt_scene_desc *desc, pt_scene **out);
 void pt_scene_destroy(pt_scene *scene);
 
@@ -148,6 +152,12 @@ int pt_intersect_batch(pt_scene *scene, const float *rays, size_t n, float *out_
 int pt_render_streams(pt_scene *scene, const pt_camera_params *camera, const pt_options *options, const pt_stream *streams, size_t n,
                       float *out_image, uint64_t *out_states, pt_stats *stats);
 
+/* processItem for ONE WorkItem, returning only the item's rectangle: out_tile is item->w * item->h * 4 floats, row-major inside the
+ * rectangle (the Image<> processItem returns, worker.h:69); *out_state (may be NULL) receives the engine state afterwards.  The frame the
+ * item belongs to never exists on the host. */
+int pt_render_item(pt_scene *scene, const pt_camera_params *camera, const pt_options *options, const pt_stream *item, float *out_tile,
+                   uint64_t *out_state, pt_stats *stats);
+
 /* processJob (worker.h:83-84, src/worker.cpp:389-424) restricted to the given tiles: every pixel is its own 1x1 stream whose
  * engine is RandomEngine(pt_pixel_seed(base_seed, x, y)) -- the reference seeds its workers from std::random_device
  * (worker.cpp:369-382), so any seeding conforms; this one makes the image independent of tiling and of the GPU count. */
@@ -160,6 +170,14 @@ int pt_render_tiles(pt_scene *scene, const pt_camera_params *camera, const pt_op
 typedef void (*pt_progress_fn)(int completed, int total, void *user);
 int pt_render_tiles_progress(pt_scene *scene, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles,
                              uint64_t base_seed, float *out_image, pt_stats *stats, pt_progress_fn progress, void *user);
+
+/* processJob on several devices of one node -- the multi-device form of doWorkParallel (src/worker.cpp:364-387).  scenes[i] are replicas of
+ * one scene created on different devices (pt_scene_create(device_i, same desc)); tile k is rendered by scenes[k % n_scenes], one host
+ * thread per scene, and the finished tiles of every device are copied into out_image.  The image is identical for every n_scenes
+ * (per-pixel engines).  stats, if not NULL, is an array of n_scenes entries; progress as in pt_render_tiles_progress, counted over
+ * all devices. */
+int pt_render_tiles_multi(pt_scene *const *scenes, int n_scenes, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles,
+                          size_t n_tiles, uint64_t base_seed, float *out_image, pt_stats *stats, pt_progress_fn progress, void *user);
 
 /* Same, writing into DEVICE memory (e.g. a torch tensor's data_ptr) and ordered on `stream` (a hipStream_t, NULL = the
  * library's own stream followed by a synchronisation).  Used for the multi-GPU gather over RCCL. */

@@ -196,9 +196,30 @@ Scene::Scene(std::vector<std::unique_ptr<Object>> &&objs, std::vector<std::uniqu
 
     const char *device_env = std::getenv("PATHTRACE_DEVICE");
     const int device = device_env != nullptr ? std::atoi(device_env) : 0;
-    if(pt_scene_create(device, &desc, &device_scene) != PT_OK) {
-        throw std::runtime_error(std::string("PathTrace: cannot create the device scene: ") + pt_last_error());
+    int n_replicas = 1;
+    if(const char *devices_env = std::getenv("PATHTRACE_DEVICES")) {
+        n_replicas = std::string(devices_env) == "all" ? pt_device_count() - device : std::atoi(devices_env);
+        n_replicas = std::max(n_replicas, 1);
     }
+    // (tests on a one-GPU box: $PATHTRACE_REPLICAS_SHARE_DEVICE = k makes k replicas on the first device)
+    int share = 0;
+    if(const char *share_env = std::getenv("PATHTRACE_REPLICAS_SHARE_DEVICE")) {
+        share = std::atoi(share_env);
+        n_replicas = std::max(n_replicas, share);
+    }
+    for(int r = 0; r < n_replicas; r++) {
+        pt_scene *replica = nullptr;
+        if(pt_scene_create(share > 0 ? device : device + r, &desc, &replica) != PT_OK) {
+            const std::string message = pt_last_error();
+            for(pt_scene *made : replicas) {
+                pt_scene_destroy(made);
+            }
+            replicas.clear();
+            throw std::runtime_error("PathTrace: cannot create the device scene on device " + std::to_string(device + r) + ": " + message);
+        }
+        replicas.push_back(replica);
+    }
+    device_scene = replicas[0];
 
     // emissive objects and their cumulative selection probabilities, in the order the hierarchy registers them
     uint64_t n_emissive = 0;
@@ -212,7 +233,9 @@ Scene::Scene(std::vector<std::unique_ptr<Object>> &&objs, std::vector<std::uniqu
 }
 
 Scene::~Scene() {
-    pt_scene_destroy(device_scene);
+    for(pt_scene *replica : replicas) {
+        pt_scene_destroy(replica);
+    }
 }
 
 std::tuple<float, const Object *> Scene::getIntersection(const Ray &ray) const noexcept {

@@ -60,17 +60,11 @@ Image<> processItem(const WorkItem &item, RandomEngine &re) {
     const pt_options options = renderOptions(job.options);
     const pt_stream stream{item.offset_x, item.offset_y, item.width, item.height, re.state()};
 
-    std::vector<float> frame(static_cast<size_t>(options.image_width) * static_cast<size_t>(options.image_height) * 4, 0.0F);
+    // the device renders into a frame that lives in HBM only; the item's rectangle comes back straight into the tile
+    static_assert(sizeof(Color<float>) == 4 * sizeof(float), "Image<Color<float>> is a packed RGBA float array");
     uint64_t state_after = stream.rng_state;
-    check(pt_render_streams(job.scene.deviceScene(), &camera, &options, &stream, 1, frame.data(), &state_after, nullptr), "processItem");
+    check(pt_render_item(job.scene.deviceScene(), &camera, &options, &stream, reinterpret_cast<float *>(tile.data()), &state_after, nullptr), "processItem");
     re.setState(state_after);
-
-    for(int y = 0; y < item.height; y++) {
-        for(int x = 0; x < item.width; x++) {
-            const float *px = &frame[(static_cast<size_t>(item.offset_y + y) * options.image_width + (item.offset_x + x)) * 4];
-            tile(x, y) = Color<float>(px[0], px[1], px[2], px[3]);
-        }
-    }
     return tile;
 }
 
@@ -97,13 +91,17 @@ Image<> processJob(const FrameRenderJob &job, const std::function<void(int, int)
         base_seed = (static_cast<uint64_t>(device()) << 32) | device();
     }
 
+    // The tiles are dealt to the scene's device replicas ($PATHTRACE_DEVICES; one by default) and rendered by one persistent launch
+    // per device.  progress_callback is called as the reference calls it (worker.h:75-78, src/worker.cpp:354-360): once per finished
+    // tile, (completed, total), never concurrently -- while the devices are still rendering.
+    struct Forward {
+        const std::function<void(int, int)> *fn;
+    } forward{&progress_callback};
+    auto trampoline = [](int completed, int total, void *user) { (*static_cast<Forward *>(user)->fn)(completed, total); };
     static_assert(sizeof(Color<float>) == 4 * sizeof(float), "Image<Color<float>> is a packed RGBA float array");
-    check(pt_render_tiles(job.scene.deviceScene(), &camera, &options, tiles.data(), tiles.size(), base_seed, reinterpret_cast<float *>(frame.data()), nullptr),
+    const std::vector<pt_scene *> &replicas = job.scene.deviceScenes();
+    check(pt_render_tiles_multi(replicas.data(), static_cast<int>(replicas.size()), &camera, &options, tiles.data(), tiles.size(), base_seed,
+                                reinterpret_cast<float *>(frame.data()), nullptr, trampoline, &forward),
           "processJob");
-
-    const int total = static_cast<int>(tiles.size());
-    for(int done = 1; done <= total; done++) {
-        progress_callback(done, total);
-    }
     return frame;
 }

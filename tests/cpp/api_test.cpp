@@ -15,9 +15,11 @@
 #include <gtest/gtest.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
 
 namespace {
 
@@ -177,6 +179,92 @@ TEST(WorkItem, ProcessJobIsReproducibleUnderAFixedSeed) {
     unsetenv("PATHTRACE_SEED");
     EXPECT_THAT(sameBits(a, b), testing::Eq(true));
     EXPECT_THAT(sameBits(a, c), testing::Eq(false));
+}
+
+TEST(WorkItem, ProgressIsReportedTileByTileWhileTheDeviceRenders) {
+    // worker.h:75-78 / src/worker.cpp:354-360: (completed, total) once per finished tile, completed = 1 .. total in order, never
+    // concurrently.  The first report must arrive well before the last one: tiles are reported as they finish, not after the frame.
+    Scene scene = boxScene();
+    Camera camera({0.0F, 0.0F, -3.0F}, {0.0F, 0.0F, 0.0F}, {0.0F, 1.0F, 0.0F}, 1.0F, 1.0F, -1.0F);
+    RenderOptions options{256, 192, 256, 256, 1E-3F};
+    FrameRenderJob job{camera, scene, options};
+    std::vector<int> seen;
+    std::vector<double> when;
+    int total_seen = -1, inside = 0, overlaps = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto frame = processJob(job, [&](int completed, int total) {
+        overlaps += inside++ != 0 ? 1 : 0;
+        seen.push_back(completed);
+        total_seen = total;
+        when.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        inside--;
+    });
+    const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    EXPECT_THAT(total_seen, testing::Eq(8 * 6)); // 256 x 192 in 32 x 32 tiles (worker.cpp:398-414)
+    EXPECT_THAT(static_cast<int>(seen.size()), testing::Eq(total_seen));
+    bool in_order = true;
+    for(size_t i = 0; i < seen.size(); i++) {
+        in_order = in_order && seen[i] == static_cast<int>(i) + 1;
+    }
+    EXPECT_THAT(in_order, testing::Eq(true));
+    EXPECT_THAT(overlaps, testing::Eq(0));
+    EXPECT_THAT(when.front() < 0.9 * all, testing::Eq(true));
+    EXPECT_THAT(frame(128, 96)[3], testing::Eq(1.0F));
+}
+
+TEST(WorkItem, ThreadsMayShareOneScene) {
+    // the reference's workers call processItem concurrently on one const Scene, each with its own engine (src/worker.cpp:328-362)
+    Scene scene = boxScene();
+    Camera camera({0.0F, 0.0F, -3.0F}, {0.0F, 0.0F, 0.0F}, {0.0F, 1.0F, 0.0F}, 1.0F, 1.0F, -1.0F);
+    RenderOptions options{64, 64, 8, 8, 1E-3F};
+    FrameRenderJob job{camera, scene, options};
+    std::vector<Image<>> alone, together(4);
+    for(int k = 0; k < 4; k++) {
+        RandomEngine re(100 + static_cast<uint64_t>(k));
+        alone.push_back(processItem(WorkItem(&job, 8 * k, 4 * k, 16, 16), re));
+    }
+    std::vector<std::thread> threads;
+    for(int k = 0; k < 4; k++) {
+        threads.emplace_back([&, k]() {
+            for(int round = 0; round < 3; round++) {
+                RandomEngine re(100 + static_cast<uint64_t>(k));
+                together[static_cast<size_t>(k)] = processItem(WorkItem(&job, 8 * k, 4 * k, 16, 16), re);
+            }
+        });
+    }
+    for(auto &t : threads) {
+        t.join();
+    }
+    for(size_t k = 0; k < 4; k++) {
+        EXPECT_THAT(sameBits(alone[k], together[k]), testing::Eq(true));
+    }
+}
+
+TEST(WorkItem, DeviceReplicasRenderTheSameFrame) {
+    // $PATHTRACE_DEVICES: the scene is replicated and processJob deals the tiles out (here: two replicas on the one device of a test box)
+    Camera camera({0.0F, 0.0F, -3.0F}, {0.0F, 0.0F, 0.0F}, {0.0F, 1.0F, 0.0F}, 1.0F, 1.0F, -1.0F);
+    RenderOptions options{96, 80, 8, 8, 1E-3F};
+    setenv("PATHTRACE_SEED", "5", 1);
+    Image<> one(0, 0), two(0, 0);
+    {
+        Scene scene = boxScene();
+        FrameRenderJob job{camera, scene, options};
+        one = processJob(job);
+    }
+    setenv("PATHTRACE_DEVICES", "1", 1);
+    setenv("PATHTRACE_REPLICAS_SHARE_DEVICE", "2", 1);
+    {
+        Scene scene = boxScene();
+        EXPECT_THAT(static_cast<int>(scene.deviceScenes().size()), testing::Eq(2));
+        FrameRenderJob job{camera, scene, options};
+        int calls = 0;
+        two = processJob(job, [&](int, int) { calls++; });
+        EXPECT_THAT(calls, testing::Eq(5 * 4)); // 96 x 80 in 20 x 20 tiles (worker.cpp:398-414)
+    }
+    unsetenv("PATHTRACE_DEVICES");
+    unsetenv("PATHTRACE_REPLICAS_SHARE_DEVICE");
+    unsetenv("PATHTRACE_SEED");
+    EXPECT_THAT(sameBits(one, two), testing::Eq(true));
 }
 
 namespace {

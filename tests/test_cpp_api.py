@@ -67,7 +67,7 @@ def test_reference_sources_compile_unchanged():
 def test_api_program_on_gpu(api_test_exe):
     r = _run(api_test_exe)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("[       OK ]") == 9, r.stdout
+    assert r.stdout.count("[       OK ]") == 12, r.stdout
 
 
 @pytest.mark.gpu

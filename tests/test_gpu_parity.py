@@ -238,6 +238,72 @@ def test_image_independent_of_tiling(gpu_scenes, sset):
     assert_bits_equal(sc.process_job(cam, opt, base_seed=7, tiles=odd), full, "ragged tiles")
 
 
+def test_work_item_returns_its_own_tile(gpu_scenes, sset):
+    """pt_render_item = processItem returning the item's rectangle only (the C++ processItem's path): the golden tiles again, and the
+    frame-sized call on the same item."""
+    g = golden("tiles")
+    cam = sset["cornell"][1]
+    sc = gpu_scenes("cornell")
+    opt = scenes.options(256, 256, 16, 64)
+    tile, state = sc.process_work_item(cam, opt, 96, 128, 32, 32, binding.seed_to_state(99))
+    assert_bits_equal(tile, g["cornell_mid_16_64"], "tile")
+    assert state == int(g["cornell_mid_state"][0])
+    img, st = sc.process_item(cam, opt, _tile_stream(96, 128, 32, 32, 99))
+    assert_bits_equal(tile, img[128:160, 96:128], "same item through the frame-sized call")
+    tile, state = sc.process_work_item(cam, opt, 3, 3, 0, 0, 1234)   # zero-area item: nothing rendered, engine untouched
+    assert tile.size == 0 and state == 1234
+    with pytest.raises(binding.PtError):
+        sc.process_work_item(cam, opt, 250, 250, 32, 32, 1)
+
+
+def test_progress_and_replicas(sset):
+    """pt_render_tiles_progress / pt_render_tiles_multi: the callback sees 1 .. n_tiles in order from the calling thread; two replicas of a
+    scene (both on this box's one GPU) deal the tiles out between them and produce the single-scene frame bit for bit."""
+    import threading
+    desc, cam = sset["box"]
+    opt = scenes.options(160, 96, 16, 16)
+    a, b = binding.Scene(desc), binding.Scene(desc)
+    try:
+        want = a.process_job(cam, opt, base_seed=9)
+        calls, threads = [], set()
+        img = a.process_job_progress(cam, opt, lambda done, total: (calls.append((done, total)), threads.add(threading.get_ident())), base_seed=9)
+        n_tiles = len(binding.job_tiles(160, 96))
+        assert calls == [(k + 1, n_tiles) for k in range(n_tiles)]
+        assert threads == {threading.get_ident()}
+        assert_bits_equal(img, want, "frame rendered with a progress callback")
+        calls.clear()
+        img2, stats = binding.process_job_multi([a, b], cam, opt, base_seed=9, progress=lambda done, total: calls.append((done, total)), want_stats=True)
+        assert_bits_equal(img2, want, "frame rendered by two replicas")
+        assert [c[0] for c in calls] == list(range(1, n_tiles + 1))
+        assert sum(s["samples"] for s in stats) == 160 * 96 * 16 and all(s["samples"] > 0 for s in stats)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_threads_share_a_scene(gpu_scenes, sset):
+    """Render calls on one scene from several threads are serialised inside the library (one workspace per scene): same results as alone."""
+    import threading
+    cam = sset["box"][1]
+    sc = gpu_scenes("box")
+    opt = scenes.options(64, 64, 8, 8)
+    alone = [sc.process_work_item(cam, opt, 8 * k, 4 * k, 16, 16, binding.seed_to_state(100 + k)) for k in range(4)]
+    got = [None] * 4
+
+    def work(k):
+        for _ in range(3):
+            got[k] = sc.process_work_item(cam, opt, 8 * k, 4 * k, 16, 16, binding.seed_to_state(100 + k))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(4):
+        assert_bits_equal(got[k][0], alone[k][0], "tile %d" % k)
+        assert got[k][1] == alone[k][1]
+
+
 def test_edge_cases(gpu_scenes, sset):
     sc = gpu_scenes("box")
     cam = sset["box"][1]
@@ -377,38 +443,6 @@ def test_mesh7m_c4_frame_and_rank_replay(mesh7m):
         covered[idx] += 1
     assert (covered == 1).all()
     assert_bits_equal(assembled.reshape(full.shape), full, "2048x2048 frame assembled from 8 ranks")
-
-
-def test_two_level_walk_matches(sset, oracle_lib):
-    """PT_WIDE=1: the traversal reads two-level records (one fetch per two levels of the tree, pt_trace.hip LDS_MODE 3).  Same closest
-    hits and the same frame, bit for bit, as the default one-level walk and as the oracle."""
-    import os
-    desc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(120, 120, scenes.DRAGON_BOX_TRANSFORM))
-    old = os.environ.get("PT_WIDE")
-    os.environ["PT_WIDE"] = "1"
-    try:
-        wide = binding.Scene(desc)
-    finally:
-        if old is None:
-            del os.environ["PT_WIDE"]
-        else:
-            os.environ["PT_WIDE"] = old
-    plain = binding.Scene(desc)
-    try:
-        rng = np.random.default_rng(3)
-        d = rng.normal(size=(100000, 3))
-        rays = np.concatenate([rng.uniform(-1, 1, (100000, 3)), d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1).astype(np.float32)
-        (tw, ow), (tp, op) = wide.get_intersection(rays), plain.get_intersection(rays)
-        assert_bits_equal(tw, tp, "closest hit t")
-        assert_bits_equal(ow, op, "closest hit object")
-        to, oo = oracle_lib.scene_create(desc).intersect(rays)
-        miss_equal(tw, to, "closest hit t vs oracle")
-        assert_bits_equal(ow[to >= 0], oo[to >= 0], "object vs oracle")
-        opt = scenes.options(256, 256, 8, 8)
-        assert_bits_equal(wide.process_job(cam, opt, base_seed=9), plain.process_job(cam, opt, base_seed=9), "frame")
-    finally:
-        wide.close()
-        plain.close()
 
 
 @pytest.mark.parametrize("world,side", [(2, 362), (4, 512), (8, 724)])

@@ -15,5 +15,5 @@ else:
 s = binding.Scene(sc)
 for _ in range(frames):
     img, st = s.process_job(cam, scenes.options(size, size, spp, spp), want_stats=True)
-    print("%.1f Msamples/s, kernel %.1f ms" % (size * size * spp / st["total_ms"] / 1e3, st["trace_ms"]), flush=True)
+    print("%.1f Msamples/s, kernel %.1f ms" % (size * size * spp / st["kernel_ms"] / 1e3, st["kernel_ms"]), flush=True)
 s.close()

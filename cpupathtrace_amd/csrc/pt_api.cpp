@@ -178,6 +178,8 @@ struct pt_scene {
     DevBuf<PtCandidate> sl_cand;
     DevBuf<uint2> path_spill, closest_out;
     DevBuf<uint32_t> walk_save;
+    DevBuf<PtPathArgs> path_args;  // the kernel's arguments in device memory
+    PtPathArgs host_path_args{};   // ... and the host copy they are uploaded from
     DevBuf<unsigned long long> path_wave_counters;
     uint32_t *host_tiles_done = nullptr; // pinned: tiles finished so far, written by the kernel (progress callback)
 
@@ -310,14 +312,24 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     }
     PtPathConfig cfg = s->path_cfg;
     const uint32_t max_grid = static_cast<uint32_t>(s->cu_count) * static_cast<uint32_t>(s->path_blocks_per_cu);
-    const uint32_t grid = std::max<uint32_t>(1U, std::min<uint32_t>(max_grid, (n + 255U) / 256U)); // every wavefront gets at least one row of 64 streams
+    // A stream's samples are sequential, so only more streams in flight shorten a job: a small job is spread over `spread` wavefronts
+    // (a few per CU: enough to hide latency, few enough that a traversal step still serves many walks) before any wavefront gets a
+    // full row of 64 slots; a large one fills the rows of every wavefront the chip holds.
+    const uint32_t spread = std::min<uint32_t>(max_grid * 4U, static_cast<uint32_t>(std::max(env_int("PT_SPREAD_WAVES", 1024), 4)));
+    uint32_t waves_wanted = (n + 63U) / 64U;                       // one row each
+    if(waves_wanted < spread) {
+        waves_wanted = std::min<uint32_t>(spread, n);              // thin rows
+    }
+    const uint32_t grid = std::max<uint32_t>(1U, std::min<uint32_t>(max_grid, (waves_wanted + 3U) / 4U));
     const uint32_t waves = grid * 4U;
-    const uint32_t rows = std::min<uint32_t>(static_cast<uint32_t>(cfg.rows), std::max<uint32_t>(1U, (n + waves * 64U - 1U) / (waves * 64U)));
+    const uint32_t slots_per_wave = std::min<uint32_t>(static_cast<uint32_t>(cfg.rows) * 64U, std::max<uint32_t>(1U, (n + waves - 1U) / waves));
+    const uint32_t rows = (slots_per_wave + 63U) / 64U;
     const uint32_t total = waves * rows * 64U;
     const uint32_t rays_per_slot = 1U + s->dev.n_lights + s->dev.n_object_samples;
     const uint32_t cap = rows * 64U * rays_per_slot;
     cfg.grid = static_cast<int>(grid);
     cfg.rows = static_cast<int>(rows);
+    cfg.slots_per_wave = static_cast<int>(slots_per_wave);
     PT_HIP(s->sl_stream.ensure(total));
     PT_HIP(s->sl_rect.ensure(total));
     PT_HIP(s->sl_cursor.ensure(total));
@@ -398,7 +410,8 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     PT_HIP(ev_begin.create());
     PT_HIP(ev_end.create());
     PT_HIP(hipEventRecord(ev_begin.e, st));
-    pt_launch_path(st, s->dev, cam, opt, S, T, Q, cfg, d_image, s->counters.ptr);
+    PT_HIP(s->path_args.ensure(1));
+    pt_launch_path(st, s->dev, cam, opt, S, T, Q, cfg, d_image, s->counters.ptr, &s->host_path_args, s->path_args.ptr);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(ev_end.e, st));
     if(T.tiles_done != nullptr) {

@@ -75,6 +75,7 @@ struct PtLocalQueue {
 struct PtPathConfig {
     int grid;             // workgroups of 256 threads
     int rows;             // rows of 64 slots per wavefront (<= PT_MAX_ROWS)
+    int slots_per_wave;   // slots a wavefront really uses (<= rows * 64; fewer for small jobs)
     int stack_lds;        // traversal stack entries per lane kept in LDS
     uint32_t spill_depth; // further entries per lane in HBM
     uint2 *spill;
@@ -88,8 +89,29 @@ struct PtPathConfig {
     unsigned long long *wave_counters; // [grid * 4 waves][8] node visits, leaf tests, rays, shadow rays, wave steps, shading passes, samples, vertices
 };
 
+// Everything the path kernel is told, in DEVICE memory: the kernel takes one pointer and reads what it needs where it needs it -- the
+// traversal loop a handful of values once, a shading pass the rest each time it runs -- instead of holding ~100 scalar registers of
+// kernel arguments live through the traversal loop (they do not fit: the compiler parked them in vector-register lanes there).
+struct PtPathArgs {
+    PtDevScene sc;
+    PtDevCamera cam;
+    PtDevOptions opt;
+    PtSlots S;
+    PtStreams T;
+    PtLocalQueue Q;
+    int rows, slots_per_wave, refill_idle, min_ready, burst_steps, leaf_min;
+    uint2 *spill;
+    uint32_t spill_depth;
+    uint32_t save_stride;
+    uint32_t *walk_save;
+    float4 *image;
+    PtDevCounters *counters;
+    unsigned long long *wave_counters;
+};
+
+// fills *host_args (which must stay valid until the launch has been issued), copies it to d_args on `stream` and launches
 void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams,
-                    PtLocalQueue queue, const PtPathConfig &cfg, float4 *image, PtDevCounters *counters);
+                    PtLocalQueue queue, const PtPathConfig &cfg, float4 *image, PtDevCounters *counters, PtPathArgs *host_args, PtPathArgs *d_args);
 int pt_path_blocks_per_cu(int stack_lds, int in_lds, size_t lds_bytes);
 size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_tris);
 // Scene::getIntersection for n rays (6 floats each): out[i] = (bits t, ref)

@@ -52,6 +52,7 @@ typedef const f4v __attribute__((address_space(1))) *glb_f4_cptr;
 typedef u2v __attribute__((address_space(3))) *lds_u2_ptr;
 typedef u2v __attribute__((address_space(1))) *glb_u2_ptr;
 typedef unsigned int __attribute__((address_space(3))) *lds_u32_ptr;
+typedef const PtPathArgs __attribute__((address_space(4))) *args_c4;
 
 template<bool IN_LDS>
 struct RecPtr {
@@ -83,6 +84,12 @@ PT_D float slab_walk(V3 lo, V3 hi, V3 o, V3 inv) {
     }
     return t_min < 0.0f ? 0.0f : t_min; // origin inside: t_min < 0 <= t_max (bounding_box.cpp:68-70)
 }
+
+// The root of the tree: its box is tested before anything else (Scene::getIntersection, scene.cpp:211-219)
+struct RootBox {
+    float lo[3], hi[3];
+    uint32_t ref;
+};
 
 // One walk (one ray) in a lane.
 struct Walk {
@@ -149,7 +156,7 @@ struct Tracer {
     }
 
     // Start a walk: Scene::getIntersection tests the root box first (scene.cpp:211-219).
-    PT_D void start(Walk &w, Rec &R, const PtDevScene &sc, float4 ro, float4 rd) const {
+    PT_D void start(Walk &w, Rec &R, const RootBox &root, float4 ro, float4 rd) const {
         w.o = v3(ro.x, ro.y, ro.z);
         w.d = v3(rd.x, rd.y, rd.z);
         w.thr = ro.w;
@@ -163,10 +170,10 @@ struct Tracer {
         w.sp = 0;
         w.occluded = false;
         w.cur = PT_REF_NONE;
-        if(sc.root_ref != PT_REF_NONE) {
-            const float t_root = slab_walk(ld3(sc.root_lo), ld3(sc.root_hi), w.o, w.inv);
+        if(root.ref != PT_REF_NONE) {
+            const float t_root = slab_walk(ld3(root.lo), ld3(root.hi), w.o, w.inv);
             if(t_root >= 0.0f) {
-                w.cur = sc.root_ref;
+                w.cur = root.ref;
                 fetch(w, R);
             }
         }
@@ -725,10 +732,21 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
 #endif
 
 template<int STACK_LDS, bool IN_LDS>
-__global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene sc, PtDevCamera cam, PtDevOptions opt, PtSlots S, PtStreams T, PtLocalQueue Q, int rows,
-                                                                    int refill_idle, int min_ready, int burst_steps, int leaf_min, uint2 *__restrict__ spill,
-                                                                    uint32_t spill_depth, uint32_t *__restrict__ walk_save, uint32_t save_stride, float4 *__restrict__ image,
-                                                                    PtDevCounters *counters, unsigned long long *__restrict__ wave_counters) {
+__global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPathArgs *__restrict__ args) {
+    // The argument block is read-only for the whole launch: it is addressed as CONSTANT memory (scalar loads; and pointers loaded from
+    // constant memory are known to be global ones, so everything reached through them stays global_load / global_store).
+    const args_c4 A4 = (args_c4)args;
+    const PtPathArgs *A = (const PtPathArgs *)A4;
+    // what the traversal loop needs, read once
+    const int rows = A->rows, slots_per_wave = A->slots_per_wave, refill_idle = A->refill_idle, min_ready = A->min_ready, burst_steps = A->burst_steps,
+              leaf_min = A->leaf_min;
+    PtLocalQueue Q = A->Q;
+    RootBox root;
+    root.ref = A->sc.root_ref;
+    for(int k = 0; k < 3; k++) {
+        root.lo[k] = A->sc.root_lo[k];
+        root.hi[k] = A->sc.root_hi[k];
+    }
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // LDS of the workgroup: traversal stacks [STACK_LDS][256] | hit records [4 waves][rows * 64] | slot words [4 waves][rows * 64] |
     // (small scenes) the whole tree and all triangle records
@@ -745,18 +763,22 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene 
     lds_u32_ptr word_l = (lds_u32_ptr)reinterpret_cast<uint32_t *>(at) + wave_in_block * n_slots;
     at += (size_t)4 * n_slots * sizeof(uint32_t);
     float4 *lds_pairs = reinterpret_cast<float4 *>(at);
-    float4 *lds_tris = lds_pairs + 4 * (size_t)sc.n_lds_pairs;
+    float4 *lds_tris = lds_pairs + 4 * (size_t)A->sc.n_lds_pairs;
 
     if(IN_LDS) {
-        for(uint32_t i = tid; i < 4 * sc.n_lds_pairs; i += 256) {
-            lds_pairs[i] = sc.pairs[i];
+        const uint32_t n_lds_pairs = A->sc.n_lds_pairs, n_lds_tris = A->sc.n_lds_tris;
+        const float4 *src_pairs = A->sc.pairs, *src_tris = A->sc.tris;
+        for(uint32_t i = tid; i < 4 * n_lds_pairs; i += 256) {
+            lds_pairs[i] = src_pairs[i];
         }
-        for(uint32_t i = tid; i < 3 * sc.n_lds_tris + 1; i += 256) { // + 1: the padding word the fourth load of the last triangle reads
-            lds_tris[i] = i < 3 * sc.n_lds_tris ? sc.tris[i] : make_float4(0, 0, 0, 0);
+        for(uint32_t i = tid; i < 3 * n_lds_tris + 1; i += 256) { // + 1: the padding word the fourth load of the last triangle reads
+            lds_tris[i] = i < 3 * n_lds_tris ? src_tris[i] : make_float4(0, 0, 0, 0);
         }
     }
     for(uint32_t i = lane; i < n_slots; i += 64) {
-        word_l[i] = 0; // no stream, nothing pending: ready to take a stream
+        // no stream, nothing pending: ready to take a stream.  (A small job uses only the first slots of every wavefront: its streams are
+        // spread over all the wavefronts the chip holds, because a stream's samples are sequential and only more wavefronts shorten the chain.)
+        word_l[i] = i < (uint32_t)slots_per_wave ? 0u : (PT_F_DONE << 16);
     }
     __syncthreads(); // the only barrier: from here on the four wavefronts of the workgroup never wait for each other
 
@@ -766,19 +788,19 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene 
         tr.tris = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_tris;
     }
     else {
-        tr.pairs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.pairs;
-        tr.tris = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.tris;
+        tr.pairs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)A->sc.pairs;
+        tr.tris = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)A->sc.tris;
     }
-    tr.spheres = sc.spheres;
+    tr.spheres = (const float4 *)(glb_f4_cptr)A->sc.spheres;
     tr.stack_l = stack_l;
-    tr.my_spill = (glb_u2_ptr)(spill + ((size_t)wave * 64 + lane) * spill_depth);
+    tr.my_spill = (glb_u2_ptr)(A->spill + ((size_t)wave * 64 + lane) * A->spill_depth);
 
     const size_t slot_base = (size_t)wave * n_slots;
     const size_t queue_base = (size_t)wave * Q.cap;
     WaveCtx ctx;
     ctx.q_head = 0;
     ctx.q_count = 0;
-    ctx.n_dead = 0;
+    ctx.n_dead = n_slots - (uint32_t)slots_per_wave;
     ctx.pool_empty = false;
 
     bool active = false;
@@ -803,152 +825,175 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene 
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
 
+    // Two nested loops.  The inner one is the hot path -- retire, hand out queued rays, a burst of traversal steps -- and contains no
+    // shading code, so its registers are allocated for it alone; it is left when a shading pass is called for (queue empty, enough
+    // slots ready) or when the wavefront has nothing left to do.  The outer one runs the shading pass.
+    bool want_pass = false;
     for(;;) {
-        // ---- 1. retire finished walks: the result goes to the slot's words in LDS ---------------------------------------------------------
-        if(active && w.cur == PT_REF_NONE) {
-            const uint32_t ls = w.dest & PT_DEST_SLOT_MASK;
-            if(w.dest & PT_DEST_SHADOW) {
-                const uint32_t j = (w.dest >> PT_DEST_J_SHIFT) & 7u;
-                // one ray less pending; an unoccluded light sample sets its visibility bit
-                __hip_atomic_fetch_add(&word_l[ls], (w.occluded ? 0u : (1u << j)) - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if(want_pass) {
+            want_pass = false;
+            w_passes++;
+#ifdef PT_PATH_TIMING
+            const unsigned long long t_pass = __builtin_amdgcn_s_memtime();
+#endif
+            // The pass reads its arguments from *A now (an opaque zero offset keeps the compiler from reading them once, above the
+            // traversal loop, and carrying them through it).
+            size_t pass_offset = 0;
+            asm volatile("" : "+s"(pass_offset));
+            const PtPathArgs *P = (const PtPathArgs *)(args_c4)((const char __attribute__((address_space(4))) *)A4 + pass_offset);
+            uint32_t *const walk_save = P->walk_save;
+            const size_t save_stride = P->save_stride;
+            // Nothing of the traversal lives in registers across a shading pass (which needs them all): the walks in progress and the
+            // lane's counters are parked in this lane's column of the save area and read back afterwards.
+            {
+                uint32_t *sv = walk_save + (size_t)wave * 64 + lane;
+                const size_t st = save_stride;
+                sv[0 * st] = __float_as_uint(w.o.x);
+                sv[1 * st] = __float_as_uint(w.o.y);
+                sv[2 * st] = __float_as_uint(w.o.z);
+                sv[3 * st] = __float_as_uint(w.d.x);
+                sv[4 * st] = __float_as_uint(w.d.y);
+                sv[5 * st] = __float_as_uint(w.d.z);
+                sv[6 * st] = __float_as_uint(w.thr);
+                sv[7 * st] = w.dest;
+                sv[8 * st] = __float_as_uint(w.best_t);
+                sv[9 * st] = w.best_ref;
+                sv[10 * st] = __float_as_uint(w.t_max);
+                sv[11 * st] = w.cur;
+                sv[12 * st] = w.sp | (w.occluded ? 0x80000000u : 0u);
+                sv[13 * st] = n_nodes;
+                sv[14 * st] = n_leaves;
+                sv[15 * st] = n_rays;
+                sv[16 * st] = n_shadow;
             }
-            else {
-                const u2v h = {__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref};
-                hit_l[ls] = h;
-                __hip_atomic_fetch_add(&word_l[ls], 0u - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll 1
+            for(uint32_t r = 0; r < (uint32_t)rows; r++) {
+                shade_row(P->sc, P->cam, P->opt, P->S, P->T, P->Q, ctx, r, lane, slot_base, queue_base, word_l, hit_l, P->image, P->counters, n_samples, n_vertices);
             }
-            active = false;
+            // the rays just written are read back by other lanes of this wavefront
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            {
+                const uint32_t *sv = walk_save + (size_t)wave * 64 + lane;
+                const size_t st = save_stride;
+                w.o = v3(__uint_as_float(sv[0 * st]), __uint_as_float(sv[1 * st]), __uint_as_float(sv[2 * st]));
+                w.d = v3(__uint_as_float(sv[3 * st]), __uint_as_float(sv[4 * st]), __uint_as_float(sv[5 * st]));
+                w.inv = slab_inverse(w.d);
+                w.thr = __uint_as_float(sv[6 * st]);
+                w.dest = sv[7 * st];
+                w.best_t = __uint_as_float(sv[8 * st]);
+                w.best_ref = sv[9 * st];
+                w.t_max = __uint_as_float(sv[10 * st]);
+                w.cur = sv[11 * st];
+                const uint32_t packed = sv[12 * st];
+                w.sp = packed & 0x7fffffffu;
+                w.occluded = (packed >> 31) != 0;
+                n_nodes = sv[13 * st];
+                n_leaves = sv[14 * st];
+                n_rays = sv[15 * st];
+                n_shadow = sv[16 * st];
+            }
+#ifdef PT_PATH_TIMING
+            t_shade += __builtin_amdgcn_s_memtime() - t_pass;
+#endif
+            // the record registers do not live across a shading pass: walks in progress fetch theirs again
+            rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+            if(active && w.cur != PT_REF_NONE) {
+                tr.fetch(w, rec);
+            }
         }
 
-        // ---- 2. idle lanes: hand out queued rays; with the queue empty, shade what has come back ----------------------------------------
-        const unsigned long long idle_mask = __ballot(!active);
-        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-        if(n_idle >= (uint32_t)refill_idle) {
-            if(ctx.q_count == 0 && ctx.n_dead < n_slots) {
-                // slots whose rays have all come back (or that wait for a stream)
-                uint32_t n_ready = 0;
-                for(uint32_t r = 0; r < (uint32_t)rows; r++) {
-                    const uint32_t word = word_l[r * 64 + lane];
-                    n_ready += (uint32_t)__popcll(__ballot(!(PT_W_FLAGS(word) & PT_F_DONE) && PT_W_PENDING(word) == 0));
+        bool finished = false;
+        for(;;) {
+            // ---- 1. retire finished walks: the result goes to the slot's words in LDS -----------------------------------------------------
+            if(active && w.cur == PT_REF_NONE) {
+                const uint32_t ls = w.dest & PT_DEST_SLOT_MASK;
+                if(w.dest & PT_DEST_SHADOW) {
+                    const uint32_t j = (w.dest >> PT_DEST_J_SHIFT) & 7u;
+                    // one ray less pending; an unoccluded light sample sets its visibility bit
+                    __hip_atomic_fetch_add(&word_l[ls], (w.occluded ? 0u : (1u << j)) - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if(n_ready >= (uint32_t)min_ready || n_idle == 64u) {
-                    w_passes++;
-#ifdef PT_PATH_TIMING
-                    const unsigned long long t_pass = __builtin_amdgcn_s_memtime();
-#endif
-                    // Nothing of the traversal lives in registers across a shading pass (which needs them all): the walks in progress
-                    // and the lane's counters are parked in this lane's column of the save area and read back afterwards, so that the
-                    // traversal loop itself never has to spill.
-                    {
-                        uint32_t *sv = walk_save + (size_t)wave * 64 + lane;
-                        const size_t st = save_stride;
-                        sv[0 * st] = __float_as_uint(w.o.x);
-                        sv[1 * st] = __float_as_uint(w.o.y);
-                        sv[2 * st] = __float_as_uint(w.o.z);
-                        sv[3 * st] = __float_as_uint(w.d.x);
-                        sv[4 * st] = __float_as_uint(w.d.y);
-                        sv[5 * st] = __float_as_uint(w.d.z);
-                        sv[6 * st] = __float_as_uint(w.thr);
-                        sv[7 * st] = w.dest;
-                        sv[8 * st] = __float_as_uint(w.best_t);
-                        sv[9 * st] = w.best_ref;
-                        sv[10 * st] = __float_as_uint(w.t_max);
-                        sv[11 * st] = w.cur;
-                        sv[12 * st] = w.sp | (w.occluded ? 0x80000000u : 0u);
-                        sv[13 * st] = n_nodes;
-                        sv[14 * st] = n_leaves;
-                        sv[15 * st] = n_rays;
-                        sv[16 * st] = n_shadow;
-                    }
-#pragma unroll 1
-                    for(uint32_t r = 0; r < (uint32_t)rows; r++) {
-                        shade_row(sc, cam, opt, S, T, Q, ctx, r, lane, slot_base, queue_base, word_l, hit_l, image, counters, n_samples, n_vertices);
-                    }
-                    // the rays just written are read back by other lanes of this wavefront
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_s_waitcnt(0);
-                    {
-                        const uint32_t *sv = walk_save + (size_t)wave * 64 + lane;
-                        const size_t st = save_stride;
-                        w.o = v3(__uint_as_float(sv[0 * st]), __uint_as_float(sv[1 * st]), __uint_as_float(sv[2 * st]));
-                        w.d = v3(__uint_as_float(sv[3 * st]), __uint_as_float(sv[4 * st]), __uint_as_float(sv[5 * st]));
-                        w.inv = slab_inverse(w.d);
-                        w.thr = __uint_as_float(sv[6 * st]);
-                        w.dest = sv[7 * st];
-                        w.best_t = __uint_as_float(sv[8 * st]);
-                        w.best_ref = sv[9 * st];
-                        w.t_max = __uint_as_float(sv[10 * st]);
-                        w.cur = sv[11 * st];
-                        const uint32_t packed = sv[12 * st];
-                        w.sp = packed & 0x7fffffffu;
-                        w.occluded = (packed >> 31) != 0;
-                        n_nodes = sv[13 * st];
-                        n_leaves = sv[14 * st];
-                        n_rays = sv[15 * st];
-                        n_shadow = sv[16 * st];
-                    }
-#ifdef PT_PATH_TIMING
-                    t_shade += __builtin_amdgcn_s_memtime() - t_pass;
-#endif
-                    // the record registers do not live across a shading pass: walks in progress fetch theirs again
-                    rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-                    if(active && w.cur != PT_REF_NONE) {
-                        tr.fetch(w, rec);
-                    }
+                else {
+                    const u2v h = {__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref};
+                    hit_l[ls] = h;
+                    __hip_atomic_fetch_add(&word_l[ls], 0u - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                active = false;
             }
-            if(ctx.q_count > 0) {
-                const uint32_t take = ctx.q_count < n_idle ? ctx.q_count : n_idle;
-                if(!active) {
-                    const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
-                    if(rank < take) {
-                        uint32_t i = ctx.q_head + rank;
-                        i = i >= Q.cap ? i - Q.cap : i;
-                        const float4 ro = Q.ray_o[queue_base + i];
-                        const float4 rd = Q.ray_d[queue_base + i];
-                        if(__float_as_uint(rd.w) != PT_DEST_NULL) {
-                            tr.start(w, rec, sc, ro, rd);
-                            active = true;
-                            n_rays++;
-                            n_shadow += (w.dest & PT_DEST_SHADOW) ? 1u : 0u;
+
+            // ---- 2. idle lanes: hand out queued rays; with the queue empty, see whether enough slots are ready for a shading pass --------
+            const unsigned long long idle_mask = __ballot(!active);
+            const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+            if(n_idle >= (uint32_t)refill_idle) {
+                if(ctx.q_count == 0 && ctx.n_dead < n_slots) {
+                    // slots whose rays have all come back (or that wait for a stream)
+                    uint32_t n_ready = 0;
+                    for(uint32_t r = 0; r < (uint32_t)rows; r++) {
+                        const uint32_t word = word_l[r * 64 + lane];
+                        n_ready += (uint32_t)__popcll(__ballot(!(PT_W_FLAGS(word) & PT_F_DONE) && PT_W_PENDING(word) == 0));
+                    }
+                    if(n_ready >= (uint32_t)min_ready || n_idle == 64u) {
+                        want_pass = true;
+                        break;
+                    }
+                }
+                if(ctx.q_count > 0) {
+                    const uint32_t take = ctx.q_count < n_idle ? ctx.q_count : n_idle;
+                    if(!active) {
+                        const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
+                        if(rank < take) {
+                            uint32_t i = ctx.q_head + rank;
+                            i = i >= Q.cap ? i - Q.cap : i;
+                            const float4 ro = Q.ray_o[queue_base + i];
+                            const float4 rd = Q.ray_d[queue_base + i];
+                            if(__float_as_uint(rd.w) != PT_DEST_NULL) {
+                                tr.start(w, rec, root, ro, rd);
+                                active = true;
+                                n_rays++;
+                                n_shadow += (w.dest & PT_DEST_SHADOW) ? 1u : 0u;
+                            }
                         }
                     }
+                    ctx.q_head += take;
+                    ctx.q_head = ctx.q_head >= Q.cap ? ctx.q_head - Q.cap : ctx.q_head;
+                    ctx.q_count -= take;
                 }
-                ctx.q_head += take;
-                ctx.q_head = ctx.q_head >= Q.cap ? ctx.q_head - Q.cap : ctx.q_head;
-                ctx.q_count -= take;
             }
-        }
-        if(__ballot(active) == 0ULL) {
-            if(ctx.q_count == 0 && ctx.n_dead >= n_slots) {
-                break; // every slot is dead, nothing queued, nothing walking
+            if(__ballot(active) == 0ULL) {
+                if(ctx.q_count == 0 && ctx.n_dead >= n_slots) {
+                    finished = true; // every slot is dead, nothing queued, nothing walking
+                    break;
+                }
+                continue;
             }
-            continue;
-        }
 
-        // ---- 3. a burst of traversal steps -------------------------------------------------------------------------------------------------
-        // Lanes that stand on a leaf wait (their order of visits is unchanged) until `leaf_min` of them can share the leaf code, or no
-        // lane has an inner node left; the leaf test then rides along with the other lanes' node step (one memory round trip for both).
+            // ---- 3. a burst of traversal steps ---------------------------------------------------------------------------------------------
+            // Lanes that stand on a leaf wait (their order of visits is unchanged) until `leaf_min` of them can share the leaf code, or no
+            // lane has an inner node left; the leaf test then rides along with the other lanes' node step (one memory round trip for both).
 #ifdef PT_PATH_TIMING
-        const unsigned long long t_b0 = __builtin_amdgcn_s_memtime();
+            const unsigned long long t_b0 = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll 1
-        for(int burst = 0; burst < burst_steps; burst++) {
-            const bool standing = active && w.cur != PT_REF_NONE;
-            const bool at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
-            const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
-            if((leaf_mask | node_mask) == 0ULL) {
-                break;
+            for(int burst = 0; burst < burst_steps; burst++) {
+                const bool standing = active && w.cur != PT_REF_NONE;
+                const bool at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
+                const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
+                if((leaf_mask | node_mask) == 0ULL) {
+                    break;
+                }
+                const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
+                w_steps++;
+                if(standing && (!at_leaf || do_leaves)) {
+                    tr.step(w, rec, n_nodes, n_leaves);
+                }
             }
-            const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
-            w_steps++;
-            if(standing && (!at_leaf || do_leaves)) {
-                tr.step(w, rec, n_nodes, n_leaves);
-            }
-        }
 #ifdef PT_PATH_TIMING
-        t_burst += __builtin_amdgcn_s_memtime() - t_b0;
+            t_burst += __builtin_amdgcn_s_memtime() - t_b0;
 #endif
+        }
+        if(finished) {
+            break;
+        }
     }
 
     // Work counters: every wave owns one 64-byte slot (plain stores; atomics on a shared line from every wave serialise at the memory side)
@@ -961,7 +1006,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(PtDevScene 
         n_vertices += __shfl_down(n_vertices, off);
     }
     if(lane == 0) {
-        unsigned long long *slot = wave_counters + 8 * (size_t)wave;
+        unsigned long long *slot = A->wave_counters + 8 * (size_t)wave;
         slot[0] += n_nodes;
         slot[1] += n_leaves;
         slot[2] += n_rays;
@@ -1017,7 +1062,13 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
     Walk w;
     typename Tracer<STACK_LDS, IN_LDS>::Rec rec;
     rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-    tr.start(w, rec, sc, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
+    RootBox root;
+    root.ref = sc.root_ref;
+    for(int k = 0; k < 3; k++) {
+        root.lo[k] = sc.root_lo[k];
+        root.hi[k] = sc.root_hi[k];
+    }
+    tr.start(w, rec, root, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
     uint32_t n_nodes = 0, n_leaves = 0;
     while(w.cur != PT_REF_NONE) {
         tr.step(w, rec, n_nodes, n_leaves);
@@ -1026,10 +1077,8 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
 }
 
 template<int STACK_LDS, bool IN_LDS>
-void launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams, PtLocalQueue queue,
-                 const PtPathConfig &cfg, float4 *image, PtDevCounters *counters) {
-    hipLaunchKernelGGL((pt_path_kernel<STACK_LDS, IN_LDS>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, scene, camera, options, slots, streams, queue, cfg.rows,
-                       cfg.refill_idle, cfg.min_ready, cfg.burst_steps, cfg.leaf_min, cfg.spill, cfg.spill_depth, cfg.walk_save, (uint32_t)cfg.grid * 256u, image, counters, cfg.wave_counters);
+void launch_path(hipStream_t stream, const PtPathConfig &cfg, const PtPathArgs *d_args) {
+    hipLaunchKernelGGL((pt_path_kernel<STACK_LDS, IN_LDS>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, d_args);
 }
 
 template<int STACK_LDS, bool IN_LDS>
@@ -1068,8 +1117,29 @@ void launch_closest(hipStream_t stream, const PtDevScene &scene, const float *ra
     } while(0)
 
 void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams,
-                    PtLocalQueue queue, const PtPathConfig &cfg, float4 *image, PtDevCounters *counters) {
-    PT_DISPATCH(launch_path, cfg, stream, scene, camera, options, slots, streams, queue, cfg, image, counters);
+                    PtLocalQueue queue, const PtPathConfig &cfg, float4 *image, PtDevCounters *counters, PtPathArgs *host_args, PtPathArgs *d_args) {
+    PtPathArgs &a = *host_args;
+    a.sc = scene;
+    a.cam = camera;
+    a.opt = options;
+    a.S = slots;
+    a.T = streams;
+    a.Q = queue;
+    a.rows = cfg.rows;
+    a.slots_per_wave = cfg.slots_per_wave;
+    a.refill_idle = cfg.refill_idle;
+    a.min_ready = cfg.min_ready;
+    a.burst_steps = cfg.burst_steps;
+    a.leaf_min = cfg.leaf_min;
+    a.spill = cfg.spill;
+    a.spill_depth = cfg.spill_depth;
+    a.save_stride = (uint32_t)cfg.grid * 256u;
+    a.walk_save = cfg.walk_save;
+    a.image = image;
+    a.counters = counters;
+    a.wave_counters = cfg.wave_counters;
+    (void)hipMemcpyAsync(d_args, host_args, sizeof(PtPathArgs), hipMemcpyHostToDevice, stream);
+    PT_DISPATCH(launch_path, cfg, stream, cfg, d_args);
 }
 
 void pt_launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg) {

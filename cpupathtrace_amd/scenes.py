@@ -335,10 +335,8 @@ def cornell_scene(width=256, height=256, mesh_pos=None, mesh_nrm=None):
 # Procedural stand-in for assets/xyzrgb_dragon.obj (absent from the reference mount)
 # ---------------------------------------------------------------------------------------------------------------------
 
-def bumpy_sphere_mesh(nu, nv, transform=None, radius=40.0, bump=0.2, centre=(0.0, 50.0, 0.0)):
-    """Closed UV sphere r = radius * (1 + bump * sin(5 theta) * sin(7 phi)) with 2*nu*(nv-1) triangles and smooth vertex
-    normals computed the way io::loadMesh(..., smooth=true) does (normalised sum of the adjacent faces' unit normals,
-    src/scene/mesh.cpp:228-267).  nu = nv = 1900 gives 7,216,200 triangles, the scale of the XYZ RGB dragon."""
+def bumpy_sphere_vertices(nu, nv, radius=40.0, bump=0.2, centre=(0.0, 50.0, 0.0)):
+    """The stand-in mesh as an indexed mesh in OBJ terms: float32 vertices (untransformed) and 0-based triangle faces."""
     theta = (np.arange(nu, dtype=np.float64) * (2.0 * np.pi / nu))
     phi = (np.arange(1, nv, dtype=np.float64) * (np.pi / nv))
     tt, pp = np.meshgrid(theta, phi, indexing="xy")  # (nv-1, nu)
@@ -346,8 +344,6 @@ def bumpy_sphere_mesh(nu, nv, transform=None, radius=40.0, bump=0.2, centre=(0.0
     ring = np.stack([r * np.sin(pp) * np.cos(tt) + centre[0], r * np.cos(pp) + centre[1], r * np.sin(pp) * np.sin(tt) + centre[2]], axis=-1)
     verts = np.concatenate([[[centre[0], centre[1] + radius, centre[2]]], ring.reshape(-1, 3), [[centre[0], centre[1] - radius, centre[2]]]])
     verts = verts.astype(F)
-    if transform is not None:
-        verts = mat4_apply(transform, verts)
     n_ring = nv - 1
     top, bottom = 0, len(verts) - 1
 
@@ -361,7 +357,16 @@ def bumpy_sphere_mesh(nu, nv, transform=None, radius=40.0, bump=0.2, centre=(0.0
         faces.append(np.stack([a, b, d], axis=1))
         faces.append(np.stack([a, d, c], axis=1))
     faces.append(np.stack([np.full(nu, bottom), vid(n_ring - 1, i), vid(n_ring - 1, i + 1)], axis=1))
-    faces = np.concatenate(faces, axis=0)
+    return verts, np.concatenate(faces, axis=0)
+
+
+def bumpy_sphere_mesh(nu, nv, transform=None, radius=40.0, bump=0.2, centre=(0.0, 50.0, 0.0)):
+    """Closed UV sphere r = radius * (1 + bump * sin(5 theta) * sin(7 phi)) with 2*nu*(nv-1) triangles and smooth vertex
+    normals computed the way io::loadMesh(..., smooth=true) does (normalised sum of the adjacent faces' unit normals,
+    src/scene/mesh.cpp:228-267).  nu = nv = 1900 gives 7,216,200 triangles, the scale of the XYZ RGB dragon."""
+    verts, faces = bumpy_sphere_vertices(nu, nv, radius, bump, centre)
+    if transform is not None:
+        verts = mat4_apply(transform, verts)
 
     tri = verts[faces]  # (n, 3, 3)
     with np.errstate(all="ignore"):

@@ -4,6 +4,8 @@
 #include <PathTrace/scene/mesh.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <vector>
 #include <sstream>
 #include <string>
 
@@ -49,6 +51,24 @@ uint64_t pth_make_box(const float *a, const float *b, uint64_t capacity, float *
 uint64_t pth_load_mesh(const char *obj_text, uint64_t len, const float *mat16, int smooth, uint64_t capacity, float *pos, float *nrm) {
     std::istringstream stream(std::string(obj_text, len));
     return store(io::loadMesh(stream, matrixFrom(mat16), false, smooth != 0), capacity, pos, nrm);
+}
+
+// Writes an indexed triangle mesh as a Wavefront OBJ file ("v x y z" with 9 significant digits -- exact for float32 -- and 1-based
+// "f a b c" lines): the committed stand-in for assets/xyzrgb_dragon.obj goes to disk this way for the reference's benchmark program.
+int pth_write_obj(const char *path, const float *vertices, uint64_t n_vertices, const int32_t *faces, uint64_t n_faces) {
+    std::FILE *f = std::fopen(path, "w");
+    if(f == nullptr) {
+        return 1;
+    }
+    std::vector<char> buffer(1 << 22);
+    std::setvbuf(f, buffer.data(), _IOFBF, buffer.size());
+    for(uint64_t i = 0; i < n_vertices; i++) {
+        std::fprintf(f, "v %.9g %.9g %.9g\n", vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]);
+    }
+    for(uint64_t i = 0; i < n_faces; i++) {
+        std::fprintf(f, "f %d %d %d\n", faces[3 * i] + 1, faces[3 * i + 1] + 1, faces[3 * i + 2] + 1);
+    }
+    return std::fclose(f) == 0 ? 0 : 1;
 }
 
 void pth_mat4_apply(const float *mat16, uint64_t n, const float *in, float *out) {

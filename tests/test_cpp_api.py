@@ -38,6 +38,8 @@ def build_reference_programs():
                                                       "scene/scene_test.cpp", "scene/mesh_test.cpp", "image/image_io_test.cpp")]
     build_host.compile_program(tests, os.path.join(REF_OUT, "ref_tests"), extra_includes=[SHIM, os.path.join(REF, "test")], extra_flags=["-O1"])
     build_host.compile_program([os.path.join(REF, "demo", "main.cpp")], os.path.join(REF_OUT, "ref_demo"), extra_flags=["-O1"])
+    # the reference's benchmark program, unchanged, against tests/cpp/shim/benchmark/benchmark.h (Google Benchmark is not installed)
+    build_host.compile_program([os.path.join(REF, "benchmark", "main.cpp")], os.path.join(REF_OUT, "ref_benchmark"), extra_includes=[SHIM], extra_flags=["-O2"])
 
 
 def test_host_library_builds_and_links():
@@ -68,6 +70,28 @@ def test_api_program_on_gpu(api_test_exe):
     r = _run(api_test_exe)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("[       OK ]") == 12, r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_benchmark_on_gpu(tmp_path):
+    """benchmark/main.cpp of the reference, compiled unchanged (benchmark/main.cpp:15-32,59-110): renderSceneBox as it is, renderSceneDragonBox
+    with the procedural stand-in mesh written where the program looks for assets/xyzrgb_dragon.obj -- the whole C++ path
+    io::loadMesh -> moveObjects -> Scene::Scene -> processJob, 128 x 128 x 256 spp per iteration.  (Here a 179,400-triangle mesh; DESIGN.md has
+    the 7.2 M-triangle run.)"""
+    import re
+    import sys
+    exe = os.path.join(REF_OUT, "ref_benchmark")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_benchmark was not built (it is compiled from /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import write_standin_obj
+    assert write_standin_obj.write(str(tmp_path / "assets" / "xyzrgb_dragon.obj"), 300) == 179400
+    r = subprocess.run([exe, "--benchmark_min_time=0.3"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rates = dict(re.findall(r"^(renderScene\w+)/real_time.*items_per_second_per_iteration=([0-9.e+]+)", r.stdout, re.M))
+    assert set(rates) == {"renderSceneBox", "renderSceneDragonBox"}, r.stdout
+    print(r.stdout)
+    assert float(rates["renderSceneBox"]) > 1e7 and float(rates["renderSceneDragonBox"]) > 1e7  # samples per second (the reference: ~1.3e6 on 8 cores)
 
 
 @pytest.mark.gpu

@@ -296,7 +296,7 @@ int setup_path(pt_scene *s) {
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 12), 1), 64);
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
     cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 12), 1), 64);
-    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 8), 1), 64);
+    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 4), 1), 64);
     if(env_int("PT_DEBUG", 0) != 0) {
         std::fprintf(stderr, "[pt] path kernel: %d CUs x %d workgroups, %d rows of slots per wavefront, stack_lds %d, scene %s, lds %zu B, spill depth %u\n", s->cu_count,
                      s->path_blocks_per_cu, cfg.rows, cfg.stack_lds, cfg.in_lds ? "in LDS" : "in HBM", cfg.lds_bytes, cfg.spill_depth);

@@ -1,10 +1,13 @@
 // src/host/c_exports.cpp -- plain-C views of a few scene-construction helpers of libPathTrace.so, so the Python test-suite can
 // compare them with the compiled reference (tests/test_oracle_vs_reference.py).  Same argument lists as the matching
 // functions of oracle/ref_shim.cpp.
+#include <PathTrace/image/image.h>
+#include <PathTrace/image/image_io.h>
 #include <PathTrace/scene/mesh.h>
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #include <sstream>
 #include <string>
@@ -69,6 +72,52 @@ int pth_write_obj(const char *path, const float *vertices, uint64_t n_vertices, 
         std::fprintf(f, "f %d %d %d\n", faces[3 * i] + 1, faces[3 * i + 1] + 1, faces[3 * i + 2] + 1);
     }
     return std::fclose(f) == 0 ? 0 : 1;
+}
+
+// io::writeRGBImage / io::readRGBImage through memory buffers (same argument lists as ref_png_write / ref_png_read of oracle/ref_png_shim.cpp)
+uint64_t pth_png_write(const float *rgba, int width, int height, unsigned char *out, uint64_t capacity) {
+    try {
+        Image<Color<float>> image(width, height);
+        for(int y = 0; y < height; y++) {
+            for(int x = 0; x < width; x++) {
+                const float *p = rgba + 4 * (static_cast<size_t>(y) * static_cast<size_t>(width) + static_cast<size_t>(x));
+                image(x, y) = Color<float>(p[0], p[1], p[2], p[3]);
+            }
+        }
+        std::ostringstream stream;
+        io::writeRGBImage(stream, image);
+        const std::string bytes = stream.str();
+        std::memcpy(out, bytes.data(), bytes.size() < capacity ? bytes.size() : capacity);
+        return bytes.size();
+    }
+    catch(...) {
+        return 0;
+    }
+}
+
+int pth_png_read(const unsigned char *data, uint64_t size, float *rgba, uint64_t capacity_pixels, int *width, int *height) {
+    try {
+        std::istringstream stream(std::string(reinterpret_cast<const char *>(data), size));
+        const auto image = io::readRGBImage(stream);
+        *width = image.getWidth();
+        *height = image.getHeight();
+        for(int y = 0; y < image.getHeight(); y++) {
+            for(int x = 0; x < image.getWidth(); x++) {
+                const uint64_t i = static_cast<uint64_t>(y) * static_cast<uint64_t>(image.getWidth()) + static_cast<uint64_t>(x);
+                if(i < capacity_pixels) {
+                    const auto c = image(x, y);
+                    rgba[4 * i] = c[0];
+                    rgba[4 * i + 1] = c[1];
+                    rgba[4 * i + 2] = c[2];
+                    rgba[4 * i + 3] = c[3];
+                }
+            }
+        }
+        return 0;
+    }
+    catch(...) {
+        return 1;
+    }
 }
 
 void pth_mat4_apply(const float *mat16, uint64_t n, const float *in, float *out) {

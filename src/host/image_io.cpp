@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <iterator>
+#include <limits>
 #include <stdexcept>
 #include <vector>
 
@@ -35,9 +36,13 @@ namespace {
         put32(out, static_cast<uint32_t>(crc32(0L, out.data() + start, static_cast<uInt>(out.size() - start))));
     }
 
+    // The reference's conversion (src/image/image_io.cpp:139-142): min(max(int(round(255.0 * v)), 0), 255) with the product in double.
+    // The float -> int conversion of its x86-64 build (cvttsd2si) yields INT_MIN for NaN and for values outside the int range, which the
+    // clamp then turns into 0 -- so NaN, +-inf and anything beyond about +-8.4e6 come out as 0 there, and do here.
     unsigned char quantise(float v) {
-        const float clamped = std::min(std::max(v, 0.0F), 1.0F);
-        return static_cast<unsigned char>(std::lround(clamped * 255.0F));
+        const double rounded = std::round(255.0 * static_cast<double>(v));
+        const int as_int = (rounded >= -2147483648.0 && rounded < 2147483648.0) ? static_cast<int>(rounded) : std::numeric_limits<int>::min();
+        return static_cast<unsigned char>(std::min(std::max(as_int, 0), 255));
     }
 
     int paeth(int a, int b, int c) {
@@ -192,6 +197,11 @@ namespace io {
             throw std::logic_error("readRGBImage: missing image data");
         }
         const size_t stride = static_cast<size_t>(width) * static_cast<size_t>(channels);
+        // deflate cannot expand by more than 1032 : 1, so a header that promises more pixels than the data can hold is refused before
+        // anything of that size is allocated (a 65535 x 65535 header on a 40-byte stream asked for 17 GB)
+        if((stride + 1) * height > packed.size() * 1032 + 4096) {
+            throw std::logic_error("readRGBImage: image data shorter than the header promises");
+        }
         std::vector<unsigned char> raw((stride + 1) * height);
         uLongf raw_size = static_cast<uLongf>(raw.size());
         if(uncompress(raw.data(), &raw_size, packed.data(), static_cast<uLong>(packed.size())) != Z_OK || raw_size != raw.size()) {

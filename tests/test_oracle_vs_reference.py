@@ -234,3 +234,57 @@ def test_post_processing_fresh_inputs(ref_lib, oracle_lib):
         img[..., 3] = rng.integers(0, 2, (h, w)).astype(F) if h > 1 else 1.0
         for steps, gamma in ((1, 1.8), (2, 1.8), (2, 2.2), (2, 0.45), (3, 1.8)):
             assert_bits_equal(oracle_lib.post_process(img, steps, gamma), ref_lib.post_process(img, steps, gamma), "post %dx%d steps %d gamma %g" % (w, h, steps, gamma))
+
+
+def test_png_codec_matches_reference():
+    """io::writeRGBImage / io::readRGBImage (src/host/image_io.cpp: own PNG framing on zlib, rows deflated in parallel) against the
+    reference's codec on libpng (oracle/_ref/libptref_png.so): the quantised bytes of a frame full of edge values (NaN, infinities, values
+    far outside [0, 1], exact .5 steps) are identical, each reader decodes the other writer's stream to the same pixels, and a stream the
+    reference refuses is refused here too."""
+    path = os.path.join(oracle.HERE, "_ref", "libptref_png.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libptref_png.so not built (needs /root/reference and a libpng)")
+    ref, host = C.CDLL(path), C.CDLL(build_host.build())
+    for lib, prefix in ((ref, "ref_"), (host, "pth_")):
+        getattr(lib, prefix + "png_write").restype = C.c_uint64
+
+    def write(lib, prefix, img):
+        h, w = img.shape[:2]
+        out = np.zeros(w * h * 8 + 4096, np.uint8)
+        n = getattr(lib, prefix + "png_write")(C.c_void_p(img.ctypes.data), C.c_int(w), C.c_int(h), C.c_void_p(out.ctypes.data), C.c_uint64(out.size))
+        assert 0 < n <= out.size
+        return out[:n].copy()
+
+    def read(lib, prefix, data, cap=1 << 20):
+        px = np.zeros((cap, 4), F)
+        w, h = C.c_int(), C.c_int()
+        rc = getattr(lib, prefix + "png_read")(C.c_void_p(data.ctypes.data), C.c_uint64(data.size), C.c_void_p(px.ctypes.data), C.c_uint64(cap), C.byref(w), C.byref(h))
+        return (None, 0, 0) if rc != 0 else (px[: w.value * h.value].reshape(h.value, w.value, 4).copy(), w.value, h.value)
+
+    rng = np.random.default_rng(21)
+    img = rng.uniform(-0.2, 1.2, (37, 53, 4)).astype(F)
+    flat = img.reshape(-1)
+    edge = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 8.4e6, 8.5e6, -8.5e6, 0.0, -0.0, 1.0, 0.5 / 255, 1.5 / 255, 254.5 / 255, 0.999999, 1.0000001, 2.0 ** -149,
+                     0.49999997 / 255, 127.5 / 255, 128.5 / 255], F)
+    flat[: len(edge)] = edge
+    flat[100:100 + 2560] = (np.arange(2560, dtype=np.float64) / 10.0 / 255.0).astype(F)   # every .1 step between quantisation levels
+    mine, theirs = write(host, "pth_", img), write(ref, "ref_", img)
+    a, w1, h1 = read(host, "pth_", mine)
+    b, w2, h2 = read(host, "pth_", theirs)       # this repository's reader on the reference's (libpng, adaptively filtered) stream
+    c, _, _ = read(ref, "ref_", mine)            # the reference's reader on this repository's stream
+    d, _, _ = read(ref, "ref_", theirs)
+    assert (w1, h1) == (53, 37) == (w2, h2)
+    assert_bits_equal(a, d, "quantised pixels: own writer + own reader vs reference writer + reference reader")
+    assert_bits_equal(b, d, "own reader on the reference's stream")
+    assert_bits_equal(c, d, "reference's reader on this repository's stream")
+    # RGB without alpha (reference: channel_count == 3 -> alpha 1), every PNG filter type, through both readers
+    import zlib
+    from tests import fuzz_corpus
+    rows = b"".join(bytes([y % 5]) + bytes(rng.integers(0, 256, 3 * 9, dtype=np.uint8)) for y in range(10))
+    rgb = np.frombuffer(fuzz_corpus.png(9, 10, 2, rows), np.uint8).copy()
+    e, _, _ = read(host, "pth_", rgb)
+    f, _, _ = read(ref, "ref_", rgb)
+    assert_bits_equal(e, f, "RGB stream with all five filter types")
+    broken = mine.copy()
+    broken[len(broken) // 2] ^= 0x40
+    assert read(ref, "ref_", broken)[0] is None and read(host, "pth_", broken)[0] is None

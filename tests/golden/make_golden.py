@@ -286,6 +286,23 @@ def gen_branches(ref):
         save("branch_" + name, **out)
 
 
+def gen_mesh_pixels(ref):
+    """F8 option sets d and e for the two mesh scenes (gen_scenes leaves them out); a generator of their own so that no other file changes."""
+    rng = np.random.default_rng(8)
+    sset = scene_set(golden_mesh())
+    for name in ("meshbox", "cornellmesh"):
+        sc, cam = sset[name]
+        h = ref.scene_create(sc)
+        for tag, (mn, mx, w, hgt) in {"d": (5, 10, 132, 68), "e": (4, 40, 48, 48)}.items():
+            px = 192
+            xs = rng.integers(0, w, px).astype(np.int32)
+            ys = rng.integers(0, hgt, px).astype(np.int32)
+            pst = states_for(rng, px)
+            img, pso = h.render_streams(cam, scenes.options(w, hgt, mn, mx), oracle.pixel_streams(xs, ys, pst))
+            save("pixels_%s_%s" % (name, tag), options=np.array([w, hgt, mn, mx], np.int32), xs=xs, ys=ys, states=pst, rgba=img[ys, xs], states_out=pso)
+        h.close()
+
+
 def post_images():
     """Frames for the post-processing fixtures: random HDR radiance with black, tiny and huge pixels; more and fewer than 1024 pixels
     (toneMap uses min(1024, pixel_count) segments, post_processing.cpp:56,90); a frame that is almost entirely one value."""
@@ -324,7 +341,7 @@ def gen_post(ref):
     save("post", **out)
 
 
-GENERATORS = {"rng": gen_rng, "prims": gen_prims, "bsdf": gen_bsdf, "camera": gen_camera, "scenes": gen_scenes, "post": gen_post, "branches": gen_branches}
+GENERATORS = {"rng": gen_rng, "prims": gen_prims, "bsdf": gen_bsdf, "camera": gen_camera, "scenes": gen_scenes, "post": gen_post, "branches": gen_branches, "mesh_pixels": gen_mesh_pixels}
 
 
 def main():

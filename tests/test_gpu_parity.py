@@ -67,8 +67,6 @@ def test_scene_test_cases():
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
 def test_pixels(gpu_scenes, sset, name, tag):
     """processItem on 1x1 WorkItems with given engines: pixel value and engine state afterwards, bit for bit."""
-    if name in ("meshbox", "cornellmesh") and tag in ("d", "e"):
-        pytest.skip("not recorded")
     g = golden("pixels_%s_%s" % (name, tag))
     cam = sset[name][1]
     img, st = gpu_scenes(name).process_item(cam, opt_from(g["options"]), binding.pixel_streams(g["xs"], g["ys"], g["states"]))

@@ -122,8 +122,6 @@ def test_scene(oracle_lib, sset, name):
 @pytest.mark.parametrize("name", SCENES)
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
 def test_pixels(oracle_lib, sset, name, tag):
-    if name in ("meshbox", "cornellmesh") and tag in ("d", "e"):
-        pytest.skip("not recorded")
     g = golden("pixels_%s_%s" % (name, tag))
     sc, cam = sset[name]
     h = oracle_lib.scene_create(sc)

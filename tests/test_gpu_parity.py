@@ -373,15 +373,15 @@ def _check_frame_against_oracle(scene, handle, cam, opt, seed, n_pixels=3000, qu
     return frame
 
 
-@pytest.mark.parametrize("which,spp_min,spp_max", [("cornell", 16, 16), ("mesh80k", 8, 8), ("cornell_adaptive", 4, 24), ("dragons16_80k", 8, 8)])
+@pytest.mark.parametrize("which,spp_min,spp_max", [("cornell", 16, 16), ("mesh80k", 8, 8), ("cornell_adaptive", 4, 24), ("dragons16_180k", 8, 8)])
 def test_full_size_frame_sampled_against_oracle(sset, oracle_lib, which, spp_min, spp_max):
     """BASELINE.json's frame size (1024 x 1024, one stream per pixel = 1 M streams in flight) checked where the oracle can follow.
-    dragons16_80k is configs[4] at 16 x 79,600 = 1.27 M triangles (the bench runs it at 16 x 7.2 M)."""
+    dragons16_180k is configs[4] at 16 x 179,400 = 2.87 M triangles (the bench runs it at 16 x 7.2 M, where the CPU oracle cannot follow)."""
     if which.startswith("cornell"):
         desc, cam = sset["cornell"]
         cam = dict(cam, aspect_ratio=-1.0)
-    elif which == "dragons16_80k":
-        desc, cam = scenes.dragon_grid_scene(*scenes.bumpy_sphere_mesh(200, 200, scenes.DRAGON_BOX_TRANSFORM), grid=4)
+    elif which == "dragons16_180k":
+        desc, cam = scenes.dragon_grid_scene(*scenes.bumpy_sphere_mesh(300, 300, scenes.DRAGON_BOX_TRANSFORM), grid=4)
     else:
         desc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(200, 200, scenes.DRAGON_BOX_TRANSFORM))
     scene = binding.Scene(desc)
@@ -391,6 +391,30 @@ def test_full_size_frame_sampled_against_oracle(sset, oracle_lib, which, spp_min
     finally:
         scene.close()
         handle.close()
+
+
+def test_configs4_at_full_size(oracle_lib):
+    """BASELINE.json configs[4] at its full size -- 16 transformed copies of the 7.2 M-triangle stand-in = 115,459,214 triangles, a 34-level
+    tree built on the device -- 1024 x 1024 at 2 spp: 512 random pixels rendered by the CPU oracle (whose tree of this size takes about 75 s
+    and 25 GB to build) with the same per-pixel engines, bit for bit."""
+    desc, cam = scenes.dragon_grid_scene(*scenes.bumpy_sphere_mesh(1900, 1900, scenes.DRAGON_BOX_TRANSFORM), grid=4)
+    assert len(desc["tri_pos"]) == 115459214
+    opt = scenes.options(1024, 1024, 2, 2)
+    scene = binding.Scene(desc)
+    try:
+        frame = scene.process_job(cam, opt, base_seed=77)
+    finally:
+        scene.close()
+    handle = oracle_lib.scene_create(desc)
+    try:
+        rng = np.random.default_rng(5)
+        xs, ys = rng.integers(0, 1024, 512).astype(np.int32), rng.integers(0, 1024, 512).astype(np.int32)
+        states = np.array([binding.seed_to_state(binding.pixel_seed(77, int(x), int(y))) for x, y in zip(xs, ys)], np.uint64)
+        want, _ = handle.render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=16)
+    finally:
+        handle.close()
+    assert_bits_equal(frame[ys, xs], want[ys, xs], "sampled pixels of the 115 M-triangle frame")
+    assert (want[ys, xs][:, 3] == 1).all()
 
 
 def test_mesh7m_frame(mesh7m):

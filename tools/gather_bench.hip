@@ -1,5 +1,5 @@
 // gather_bench.hip -- how fast can gfx950 fetch random 64-byte records (BVH node pairs) from a table far larger than L2?
-// Variants: (A) each lane loads its own record with 4 x global_load_dwordx4 (what pt_trace_kernel does),
+// Variants: (A) each lane loads its own record with 4 x global_load_dwordx4 (what the path kernel does per traversal step),
 //           (B) quad-cooperative: 4 adjacent lanes load the 4 x 16-byte pieces of one record in ONE instruction (the texture
 //               addresser sees one 64-byte request per quad), 4 instructions cover the 4 records of the quad, pieces are
 //               exchanged through LDS,

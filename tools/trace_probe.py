@@ -1,4 +1,4 @@
-"""Times pt_intersect_batch (the traversal kernel alone) on random rays; run under rocprofv3 --kernel-trace for kernel durations."""
+"""Times pt_intersect_batch (pt_closest_kernel: the traversal alone) on random rays; run under rocprofv3 --kernel-trace for kernel durations."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

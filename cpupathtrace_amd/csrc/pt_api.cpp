@@ -296,7 +296,7 @@ int setup_path(pt_scene *s) {
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 12), 1), 64);
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
     cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 12), 1), 64);
-    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 4), 1), 64);
+    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", cfg.in_lds ? 8 : 4), 1), 64); // measured: 4 for trees in HBM, 8 for scenes in LDS
     if(env_int("PT_DEBUG", 0) != 0) {
         std::fprintf(stderr, "[pt] path kernel: %d CUs x %d workgroups, %d rows of slots per wavefront, stack_lds %d, scene %s, lds %zu B, spill depth %u\n", s->cu_count,
                      s->path_blocks_per_cu, cfg.rows, cfg.stack_lds, cfg.in_lds ? "in LDS" : "in HBM", cfg.lds_bytes, cfg.spill_depth);
@@ -454,6 +454,11 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
         if(kcycles[0] != 0 && env_int("PT_DEBUG", 0) != 0) {
             std::fprintf(stderr, "[pt] wave time: %.1f %% in shading passes, %.1f %% in traversal bursts (of the waves' lifetimes; %llu kilo-cycles in all)\n",
                          100.0 * static_cast<double>(kcycles[2]) / static_cast<double>(kcycles[0]), 100.0 * static_cast<double>(kcycles[1]) / static_cast<double>(kcycles[0]), kcycles[0]);
+        }
+        PtDevCounters done{};
+        PT_HIP(hipMemcpy(&done, s->counters.ptr, sizeof(done), hipMemcpyDeviceToHost));
+        if(done.streams_done != T.n) {
+            return fail(PT_ERR_HIP, "path kernel ended with " + std::to_string(done.streams_done) + " of " + std::to_string(T.n) + " streams finished");
         }
         stats->node_visits = sum[0];
         stats->leaf_tests = sum[1];

@@ -112,16 +112,11 @@ struct PtCandidate {
     int32_t pad[3];
 };
 
-// Counters one render accumulates on the device (read back into pt_stats).
+// What a launch of the path kernel reports besides the per-wave work counters: streams that rendered their whole rectangle
+// (the host checks it against the number of streams when statistics are read back).
 struct PtDevCounters {
-    unsigned long long samples;
-    unsigned long long rays;
-    unsigned long long shadow_rays;
-    unsigned long long node_visits;
-    unsigned long long leaf_tests;
-    unsigned long long vertices;
     unsigned long long streams_done;
-    unsigned long long pad;
+    unsigned long long pad[7];
 };
 
 #endif

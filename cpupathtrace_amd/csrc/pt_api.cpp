@@ -326,7 +326,11 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     const uint32_t rows = (slots_per_wave + 63U) / 64U;
     const uint32_t total = waves * rows * 64U;
     const uint32_t rays_per_slot = 1U + s->dev.n_lights + s->dev.n_object_samples;
-    const uint32_t cap = rows * 64U * rays_per_slot;
+    uint32_t cap = rows * 64U * rays_per_slot;
+    const int ring_log = env_int("PT_RING_LOG_RAYS", 0); // diagnostic: rings that never wrap keep every ray of the frame (pt_debug_replay_rays)
+    if(ring_log > 0) {
+        cap = std::max<uint32_t>(cap, static_cast<uint32_t>(ring_log));
+    }
     cfg.grid = static_cast<int>(grid);
     cfg.rows = static_cast<int>(rows);
     cfg.slots_per_wave = static_cast<int>(slots_per_wave);
@@ -347,6 +351,9 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     PT_HIP(s->sl_cand.ensure(static_cast<size_t>(total) * PT_MAX_CANDIDATES));
     PT_HIP(s->lq_ray_o.ensure(static_cast<size_t>(waves) * cap));
     PT_HIP(s->lq_ray_d.ensure(static_cast<size_t>(waves) * cap));
+    if(ring_log > 0) {
+        PT_HIP(hipMemsetAsync(s->lq_ray_d.ptr, 0xff, static_cast<size_t>(waves) * cap * 4 * sizeof(float), s->stream));
+    }
     PT_HIP(s->path_spill.ensure(static_cast<size_t>(waves) * 64U * cfg.spill_depth));
     PT_HIP(s->path_wave_counters.ensure(static_cast<size_t>(waves) * 8U));
     PT_HIP(s->walk_save.ensure(static_cast<size_t>(waves) * 64U * PT_WALK_SAVE_WORDS));
@@ -1083,6 +1090,97 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
         }
         return PT_OK;
     }
+}
+
+// Diagnostic, not part of include/pt_hip.h: replays the rays the last render left in its rings (PT_RING_LOG_RAYS) through the traversal
+// alone, at `waves_per_simd` wavefronts per SIMD with every ring cut into `parts`.  out[0..4] = rays, node visits, leaf tests, wave
+// steps, checksum; *out_ms = kernel time; *out_blocks = resident workgroups per CU.
+extern "C" int pt_debug_replay_rays(pt_scene *s, int waves_per_simd, int parts, unsigned long long *out, float *out_ms, int *out_blocks) {
+    if(s == nullptr || out == nullptr || out_ms == nullptr || out_blocks == nullptr || parts < 1 || s->path_waves == 0) {
+        return fail(PT_ERR_INVALID, "nothing to replay");
+    }
+    std::lock_guard<std::mutex> lock(s->render_mutex);
+    PT_HIP(hipSetDevice(s->device));
+    PtPathConfig cfg = s->path_cfg;
+    const uint32_t waves = s->path_waves * static_cast<uint32_t>(parts);
+    PT_HIP(s->path_spill.ensure(static_cast<size_t>(waves) * 64U * cfg.spill_depth));
+    PT_HIP(s->path_wave_counters.ensure(8));
+    PT_HIP(hipMemsetAsync(s->path_wave_counters.ptr, 0, 8 * sizeof(unsigned long long), s->stream));
+    PtLocalQueue Q{};
+    Q.ray_o = reinterpret_cast<float4 *>(s->lq_ray_o.ptr);
+    Q.ray_d = reinterpret_cast<float4 *>(s->lq_ray_d.ptr);
+    Q.cap = s->path_cap;
+    Event e0, e1;
+    PT_HIP(e0.create());
+    PT_HIP(e1.create());
+    PT_HIP(hipEventRecord(e0.e, s->stream));
+    *out_blocks = pt_launch_replay(s->stream, s->dev, Q, s->path_waves, static_cast<uint32_t>(parts), waves_per_simd, cfg, s->path_spill.ptr, s->path_wave_counters.ptr);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipEventRecord(e1.e, s->stream));
+    PT_HIP(hipMemcpyAsync(out, s->path_wave_counters.ptr, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    PT_HIP(hipStreamSynchronize(s->stream));
+    PT_HIP(hipEventElapsedTime(out_ms, e0.e, e1.e));
+    return PT_OK;
+}
+
+// Diagnostic, not part of include/pt_hip.h: rewrites the pair records of a scene in another ORDER (the tree is the same: only the
+// positions of the records and the child references in them change), to measure what the memory layout is worth.  The records come
+// out in treelets of `levels` levels (breadth-first inside a treelet, treelets depth-first); levels = 1 is a depth-first pre-order.
+extern "C" int pt_debug_relayout_pairs(pt_scene *s, int levels) {
+    if(s == nullptr || levels < 1 || s->pairs.ptr == nullptr || s->dev.n_pairs == 0 || (s->dev.root_ref & PT_REF_LEAF) != 0) {
+        return fail(PT_ERR_INVALID, "nothing to lay out");
+    }
+    std::lock_guard<std::mutex> lock(s->render_mutex);
+    PT_HIP(hipSetDevice(s->device));
+    const size_t n = s->dev.n_pairs;
+    std::vector<F4> old_rec(4 * n), new_rec(4 * n);
+    PT_HIP(hipMemcpy(old_rec.data(), s->pairs.ptr, old_rec.size() * sizeof(F4), hipMemcpyDeviceToHost));
+    auto child = [&](uint32_t node, int k) { return bits(k == 0 ? old_rec[4 * static_cast<size_t>(node) + 3].x : old_rec[4 * static_cast<size_t>(node) + 3].y); };
+    std::vector<uint32_t> pos(n, PT_REF_NONE), order;
+    order.reserve(n);
+    std::vector<uint32_t> roots{s->dev.root_ref & PT_REF_INDEX}, level, next;
+    while(!roots.empty()) {
+        const uint32_t r = roots.back();
+        roots.pop_back();
+        level.assign(1, r);
+        std::vector<uint32_t> frontier;
+        for(int d = 0; d < levels && !level.empty(); d++) {
+            next.clear();
+            for(uint32_t node : level) {
+                pos[node] = static_cast<uint32_t>(order.size());
+                order.push_back(node);
+                for(int k = 0; k < 2; k++) {
+                    const uint32_t c = child(node, k);
+                    if(c != PT_REF_NONE && (c & PT_REF_LEAF) == 0) {
+                        next.push_back(c);
+                    }
+                }
+            }
+            level.swap(next);
+        }
+        for(size_t i = level.size(); i-- > 0;) { // the leftmost treelet below comes next
+            roots.push_back(level[i]);
+        }
+    }
+    if(order.size() > n) {
+        return fail(PT_ERR_INVALID, "pair records reached twice");
+    }
+    // (the breadth-first array has unused slots where a sibling pair was aligned to a line: the new order is dense, the tail stays empty)
+    for(size_t i = 0; i < order.size(); i++) {
+        const uint32_t src = order[i];
+        for(int q = 0; q < 4; q++) {
+            new_rec[4 * i + q] = old_rec[4 * static_cast<size_t>(src) + q];
+        }
+        for(int k = 0; k < 2; k++) {
+            const uint32_t c = child(src, k);
+            if(c != PT_REF_NONE && (c & PT_REF_LEAF) == 0) {
+                (k == 0 ? new_rec[4 * i + 3].x : new_rec[4 * i + 3].y) = from_bits(pos[c]);
+            }
+        }
+    }
+    PT_HIP(hipMemcpy(s->pairs.ptr, new_rec.data(), new_rec.size() * sizeof(F4), hipMemcpyHostToDevice));
+    s->dev.root_ref = pos[s->dev.root_ref & PT_REF_INDEX];
+    return PT_OK;
 }
 
 int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_stream *streams, size_t n, float *out_image,

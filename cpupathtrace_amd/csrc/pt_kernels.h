@@ -115,6 +115,9 @@ void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCame
 int pt_path_blocks_per_cu(int stack_lds, int in_lds, size_t lds_bytes);
 size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_tris);
 // Scene::getIntersection for n rays (6 floats each): out[i] = (bits t, ref)
+// diagnostic (tools/replay_probe.py): the traversal alone over the rays a render left in its rings; returns the resident workgroups per CU
+int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueue &Q, uint32_t n_logs, uint32_t parts, int waves_per_simd, const PtPathConfig &cfg,
+                     uint2 *spill, unsigned long long *out);
 void pt_launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg);
 
 

@@ -182,6 +182,13 @@ struct Tracer {
     // One step of a walk standing on a node or a leaf (w.cur != PT_REF_NONE) whose record R was fetched when the walk got there;
     // fetches the record of where the walk goes next.
     PT_D void step(Walk &w, Rec &R, uint32_t &n_nodes, uint32_t &n_leaves) const {
+        advance(w, R, n_nodes, n_leaves);
+        if(w.cur != PT_REF_NONE) {
+            fetch(w, R);
+        }
+    }
+    // ... the same without the fetch
+    PT_D void advance(Walk &w, const Rec &R, uint32_t &n_nodes, uint32_t &n_leaves) const {
         const bool is_leaf = (w.cur & PT_REF_LEAF) != 0;
         bool need_pop = false;
         const float4 q0 = to_f4(R.r0), q1 = to_f4(R.r1), q2 = to_f4(R.r2), q3 = to_f4(R.r3);
@@ -253,9 +260,6 @@ struct Tracer {
                     break;
                 }
             }
-        }
-        if(w.cur != PT_REF_NONE) {
-            fetch(w, R);
         }
     }
 };
@@ -1076,6 +1080,141 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
     out[gid] = make_uint2(__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref);
 }
 
+// ---- diagnostic: the traversal alone on the rays of a finished render ----------------------------------------------------------------
+// With PT_RING_LOG_RAYS set, the wavefronts' rings are long enough never to wrap, so after a render they hold every ray of the frame
+// in the order the wavefront traced them.  This kernel replays them: the same hand-out / burst / leaf-batching loop as the path
+// kernel, no shading, results folded into a checksum -- at WAVES wavefronts per SIMD, which the path kernel cannot choose freely
+// (the shading code's registers cap it at four).  It answers what a tracer that is not tied to the shading code would deliver.
+// Wavefront v replays part (v / n_logs) of `parts` equal parts of ring (v % n_logs).
+template<int STACK_LDS, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, PtLocalQueue Q, uint32_t n_logs, uint32_t parts, int refill_idle, int burst_steps,
+                                                                int leaf_min, uint2 *__restrict__ spill, uint32_t spill_depth,
+                                                                unsigned long long *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)tid & 63u;
+    const uint32_t wave = blockIdx.x * 4u + ((uint32_t)tid >> 6);
+    if(wave >= n_logs * parts) {
+        return;
+    }
+    Tracer<STACK_LDS, false> tr;
+    tr.pairs = (glb_f4_cptr)sc.pairs;
+    tr.tris = (glb_f4_cptr)sc.tris;
+    tr.spheres = sc.spheres;
+    tr.stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(lds_raw) + tid;
+    tr.my_spill = (glb_u2_ptr)(spill + ((size_t)wave * 64 + lane) * spill_depth);
+    RootBox root;
+    root.ref = sc.root_ref;
+    for(int k = 0; k < 3; k++) {
+        root.lo[k] = sc.root_lo[k];
+        root.hi[k] = sc.root_hi[k];
+    }
+    const size_t base = (size_t)(wave % n_logs) * Q.cap;
+    // rays written: the prefix of the ring whose direction words are not the 0xff fill
+    uint32_t lo = 0, hi = Q.cap;
+    while(lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if(__float_as_uint(Q.ray_d[base + mid].x) == 0xffffffffu) {
+            hi = mid;
+        }
+        else {
+            lo = mid + 1;
+        }
+    }
+    const uint32_t part = wave / n_logs;
+    uint32_t pos = (uint32_t)((unsigned long long)lo * part / parts);
+    const uint32_t end = (uint32_t)((unsigned long long)lo * (part + 1) / parts);
+
+    bool active = false;
+    Walk w;
+    w.o = v3(0, 0, 0);
+    w.d = v3(0, 0, 1);
+    w.inv = v3(0, 0, 0);
+    w.thr = 0.0f;
+    w.dest = 0;
+    w.best_t = 0.0f;
+    w.best_ref = PT_REF_NONE;
+    w.t_max = FLT_MAX;
+    w.cur = PT_REF_NONE;
+    w.sp = 0;
+    w.occluded = false;
+    typename Tracer<STACK_LDS, false>::Rec rec;
+    rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, checksum = 0, w_steps = 0;
+    for(;;) {
+        if(active && w.cur == PT_REF_NONE) {
+            checksum += (w.dest & PT_DEST_SHADOW) ? (w.occluded ? 1u : 2u) : (w.best_ref ^ __float_as_uint(w.best_t));
+            active = false;
+        }
+        const unsigned long long idle_mask = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if(n_idle >= (uint32_t)refill_idle && pos < end) {
+            const uint32_t left = end - pos;
+            const uint32_t take = left < n_idle ? left : n_idle;
+            if(!active) {
+                const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
+                if(rank < take) {
+                    const float4 ro = Q.ray_o[base + pos + rank];
+                    const float4 rd = Q.ray_d[base + pos + rank];
+                    if(__float_as_uint(rd.w) != PT_DEST_NULL) {
+                        tr.start(w, rec, root, ro, rd);
+                        active = true;
+                        n_rays++;
+                    }
+                }
+            }
+            pos += take;
+        }
+        if(__ballot(active) == 0ULL) {
+            if(pos >= end) {
+                break;
+            }
+            continue;
+        }
+#pragma unroll 1
+        for(int burst = 0; burst < burst_steps; burst++) {
+            const bool standing = active && w.cur != PT_REF_NONE;
+            const bool at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
+            const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
+            if((leaf_mask | node_mask) == 0ULL) {
+                break;
+            }
+            const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
+            w_steps++;
+            if(standing && (!at_leaf || do_leaves)) {
+                tr.step(w, rec, n_nodes, n_leaves);
+            }
+        }
+    }
+    for(int off = 32; off > 0; off >>= 1) {
+        n_nodes += __shfl_down(n_nodes, off);
+        n_leaves += __shfl_down(n_leaves, off);
+        n_rays += __shfl_down(n_rays, off);
+        checksum += __shfl_down(checksum, off);
+    }
+    if(lane == 0) {
+        atomicAdd(&out[0], (unsigned long long)n_rays);
+        atomicAdd(&out[1], (unsigned long long)n_nodes);
+        atomicAdd(&out[2], (unsigned long long)n_leaves);
+        atomicAdd(&out[3], (unsigned long long)w_steps);
+        atomicAdd(&out[4], (unsigned long long)checksum);
+    }
+}
+
+template<int STACK_LDS, int WAVES>
+int launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueue &Q, uint32_t n_logs, uint32_t parts, const PtPathConfig &cfg, uint2 *spill,
+                  unsigned long long *out) {
+    const size_t lds = (size_t)STACK_LDS * 256 * sizeof(uint2);
+    int blocks = 0;
+    if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_replay_kernel<STACK_LDS, WAVES>, 256, lds) != hipSuccess) {
+        blocks = -1;
+    }
+    const uint32_t waves = n_logs * parts;
+    hipLaunchKernelGGL((pt_replay_kernel<STACK_LDS, WAVES>), dim3((waves + 3) / 4), dim3(256), lds, stream, scene, Q, n_logs, parts, cfg.refill_idle,
+                       cfg.burst_steps, cfg.leaf_min, spill, cfg.spill_depth, out);
+    return blocks;
+}
+
 template<int STACK_LDS, bool IN_LDS>
 void launch_path(hipStream_t stream, const PtPathConfig &cfg, const PtPathArgs *d_args) {
     hipLaunchKernelGGL((pt_path_kernel<STACK_LDS, IN_LDS>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, d_args);
@@ -1147,6 +1286,17 @@ void pt_launch_closest(hipStream_t stream, const PtDevScene &scene, const float 
         return;
     }
     PT_DISPATCH(launch_closest, cfg, stream, scene, rays6, n, out, cfg);
+}
+
+int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueue &Q, uint32_t n_logs, uint32_t parts, int waves_per_simd, const PtPathConfig &cfg,
+                     uint2 *spill, unsigned long long *out) {
+    switch(waves_per_simd) {
+    case 4: return launch_replay<8, 4>(stream, scene, Q, n_logs, parts, cfg, spill, out);
+    case 5: return launch_replay<8, 5>(stream, scene, Q, n_logs, parts, cfg, spill, out);
+    case 6: return launch_replay<8, 6>(stream, scene, Q, n_logs, parts, cfg, spill, out);
+    case 7: return launch_replay<8, 7>(stream, scene, Q, n_logs, parts, cfg, spill, out);
+    default: return launch_replay<8, 8>(stream, scene, Q, n_logs, parts, cfg, spill, out);
+    }
 }
 
 size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_tris) {

@@ -6,7 +6,7 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = "pt_path" if "pt_path" in k else "pt_closest" if "pt_closest" in k else None
+        k = "pt_path" if "pt_path" in k else "pt_closest" if "pt_closest" in k else "pt_replay" if "pt_replay" in k else None
         if k is None:
             continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])

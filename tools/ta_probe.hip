@@ -6,6 +6,8 @@
 //   mode 2: every lane 4 x global_load_dword from its own record (same lines, a quarter of the bytes)
 //   mode 3: every lane 1 x global_load_dwordx4 from its own record
 //   mode 4: every lane 2 x global_load_dwordx4 from its own record (32-byte records)
+//   mode 5: quad-cooperative straight into LDS (global_load_lds_dwordx4: region i holds the records of the quads' lanes i), then every
+//           lane reads its own record back with 4 x ds_read_b128 -- the full price of delivering a whole record to its lane
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -16,8 +18,17 @@
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
+template<int I>
+__device__ __forceinline__ void coop_lds(const f4v *recs, uint32_t r, int lane, unsigned char *region) {
+    const uint32_t ri = __builtin_amdgcn_update_dpp(0u, r, (I | I << 2 | I << 4 | I << 6), 0xf, 0xf, false);
+    const f4v *a = recs + 4 * (size_t)ri + (lane & 3);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)a, (__attribute__((address_space(3))) void *)(region + I * 1024), 16, 0, 0);
+}
+
 template<int MODE>
 __global__ __launch_bounds__(256, 4) void probe(const f4v *__restrict__ recs, uint32_t mask, int iters, float *out) {
+    __shared__ __align__(16) unsigned char lds_rec[MODE == 5 ? 2 * 4 * 4096 : 16];
+    unsigned char *my_region = lds_rec + (threadIdx.x >> 6) * 4096;
     uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
     f4v acc = {0, 0, 0, 0};
     const int lane = threadIdx.x & 63;
@@ -43,6 +54,15 @@ __global__ __launch_bounds__(256, 4) void probe(const f4v *__restrict__ recs, ui
             }
             else if(MODE == 3) {
                 acc += recs[4 * (size_t)r];
+            }
+            else if(MODE == 5) {
+                unsigned char *region = my_region + u * 16384; // two sets in flight
+                coop_lds<0>(recs, r, lane, region);
+                coop_lds<1>(recs, r, lane, region);
+                coop_lds<2>(recs, r, lane, region);
+                coop_lds<3>(recs, r, lane, region);
+                const f4v *rec = (const f4v *)(region + (lane & 3) * 1024 + (lane >> 2) * 64);
+                acc += rec[0] + rec[1] + rec[2] + rec[3];
             }
             else {
                 const f4v *p = recs + 4 * (size_t)r;
@@ -71,7 +91,7 @@ int main(int argc, char **argv) {
         f4v *recs;
         CHECK(hipMalloc(&recs, (size_t)n * 64));
         CHECK(hipMemset(recs, 0, (size_t)n * 64));
-        for(int mode = 0; mode < 5; mode++) {
+        for(int mode = 0; mode < 6; mode++) {
             float best = 1e30f;
             for(int rep = 0; rep < 3; rep++) {
                 CHECK(hipEventRecord(e0));
@@ -81,7 +101,8 @@ int main(int argc, char **argv) {
                 case 1: hipLaunchKernelGGL(probe<1>, grid, block, 0, 0, recs, n - 1, iters, out); break;
                 case 2: hipLaunchKernelGGL(probe<2>, grid, block, 0, 0, recs, n - 1, iters, out); break;
                 case 3: hipLaunchKernelGGL(probe<3>, grid, block, 0, 0, recs, n - 1, iters, out); break;
-                default: hipLaunchKernelGGL(probe<4>, grid, block, 0, 0, recs, n - 1, iters, out); break;
+                case 4: hipLaunchKernelGGL(probe<4>, grid, block, 0, 0, recs, n - 1, iters, out); break;
+                default: hipLaunchKernelGGL(probe<5>, grid, block, 0, 0, recs, n - 1, iters, out); break;
                 }
                 CHECK(hipEventRecord(e1));
                 CHECK(hipEventSynchronize(e1));

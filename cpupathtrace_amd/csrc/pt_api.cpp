@@ -482,6 +482,15 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
         if(env_int("PT_DEBUG", 0) != 0) {
             std::fprintf(stderr, "[pt] path kernel: %.2f ms, grid %d x 256, %d rows; wave steps %llu (%.1f lanes of 64 busy per step), shading passes %llu, rays %llu\n", ms, cfg.grid,
                          cfg.rows, sum[4], sum[4] ? static_cast<double>(sum[0] + sum[1]) / static_cast<double>(sum[4]) : 0.0, sum[5], sum[2]);
+            // balance: a wavefront's busy time follows its steps; the launch lasts as long as the busiest one
+            std::vector<unsigned long long> steps(s->path_waves);
+            for(size_t w = 0; w < steps.size(); w++) {
+                steps[w] = slots[8 * w + 4] & 0xffffffffULL;
+            }
+            std::sort(steps.begin(), steps.end());
+            const double mean = static_cast<double>(sum[4]) / static_cast<double>(steps.size());
+            std::fprintf(stderr, "[pt] wave steps per wavefront: mean %.0f, min %llu, median %llu, 90 %% %llu, 99 %% %llu, max %llu (max / mean %.3f)\n", mean, steps.front(),
+                         steps[steps.size() / 2], steps[steps.size() * 9 / 10], steps[steps.size() * 99 / 100], steps.back(), static_cast<double>(steps.back()) / mean);
         }
     }
     return PT_OK;

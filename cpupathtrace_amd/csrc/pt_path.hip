@@ -395,14 +395,31 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
         rect = S.rect[p];
         cursor = S.cursor[p];
         if(flags & PT_F_IN_FLIGHT) {
-            out = c4(S.out[p]);
-            // shadow rays of the previous vertex, in light order (worker.cpp:76-103)
+            // Everything the slot may need is requested here, in one batch (one memory round trip instead of one per use): the path
+            // state, and -- a single word, to bring the line into the caches -- the shading record of the triangle that was hit, which
+            // is the one access of this pass that usually comes from HBM.
+            const float4 out4 = S.out[p];
             uint32_t mask = S.nee_mask[p];
+            const float4 o4 = S.ray_o[p], d4 = S.ray_d[p], spectrum4 = S.spectrum[p];
+            const double divisor_in = S.divisor[p], bounce_pd_in = S.bounce_pd[p];
+            const int path_length_in = S.path_length[p];
+            uint32_t warm = 0;
+            if(flags & PT_F_HAS_EXT) {
+                const u2v h = hit_l[ls];
+                hit_t = __uint_as_float(h.x);
+                hit_ref = h.y;
+                if(!(hit_t < 0.0f) && !(hit_ref & PT_REF_SPHERE)) {
+                    warm = *reinterpret_cast<const uint32_t *>(sc.tri_shade + 8 * (size_t)(hit_ref & PT_REF_INDEX));
+                }
+            }
+            out = c4(out4);
+            // shadow rays of the previous vertex, in light order (worker.cpp:76-103)
             for(uint32_t j = 0; mask != 0; j++, mask >>= 1) {
                 if((mask & 1u) && ((vis_bits >> j) & 1u)) {
                     out = out + c4(S.nee[(size_t)j * S.total + p]);
                 }
             }
+            asm volatile("" ::"v"(warm)); // (the word itself is not used)
             if(flags & PT_F_OVERLAP) {
                 // the previous sample is complete now (worker.cpp:141-145, 196-237); it was collected (it had a vertex), it is
                 // not the pixel's last sample and the estimator cannot accept at it (see estimator_safe_to_overlap)
@@ -419,14 +436,9 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
                 out = c4(0, 0, 0, 0);
             }
             bool finished = true;
-            if(flags & PT_F_HAS_EXT) {
-                const u2v h = hit_l[ls];
-                hit_t = __uint_as_float(h.x);
-                hit_ref = h.y;
-                if(!(hit_t < 0.0f)) {
-                    finished = false;
-                    shade_vertex = true;
-                }
+            if((flags & PT_F_HAS_EXT) && !(hit_t < 0.0f)) {
+                finished = false;
+                shade_vertex = true;
             }
             if(finished) {
                 // getSample returns (worker.cpp:141-145); run the estimator
@@ -455,14 +467,13 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
                 start_sample = true;
             }
             else {
-                const float4 o4 = S.ray_o[p], d4 = S.ray_d[p];
                 ro = v3(o4.x, o4.y, o4.z);
                 rd = v3(d4.x, d4.y, d4.z);
                 contribution_unweighted = o4.w;
-                spectrum = c4(S.spectrum[p]);
-                divisor = S.divisor[p];
-                bounce_pd = S.bounce_pd[p];
-                path_length = S.path_length[p];
+                spectrum = c4(spectrum4);
+                divisor = divisor_in;
+                bounce_pd = bounce_pd_in;
+                path_length = path_length_in;
             }
         }
         else {

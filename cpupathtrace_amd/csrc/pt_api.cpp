@@ -168,7 +168,7 @@ struct pt_scene {
     PtPathConfig path_cfg{};
     int path_blocks_per_cu = 0;
     uint32_t path_slots = 0, path_waves = 0, path_cap = 0;
-    DevBuf<uint32_t> sl_stream, sl_nee_mask, pull_counter, tile_left;
+    DevBuf<uint32_t> sl_stream, pull_counter, tile_left;
     DevBuf<int4> sl_rect, st_rect;
     DevBuf<int32_t> sl_cursor, sl_path_length;
     DevBuf<uint64_t> sl_rng, st_rng;
@@ -345,7 +345,6 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     PT_HIP(s->sl_divisor.ensure(total));
     PT_HIP(s->sl_bounce_pd.ensure(total));
     PT_HIP(s->sl_path_length.ensure(total));
-    PT_HIP(s->sl_nee_mask.ensure(total));
     PT_HIP(s->sl_nee.ensure(static_cast<size_t>(total) * std::max<uint32_t>(rays_per_slot - 1U, 1U)));
     PT_HIP(s->sl_est.ensure(total));
     PT_HIP(s->sl_cand.ensure(static_cast<size_t>(total) * PT_MAX_CANDIDATES));
@@ -391,7 +390,6 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     S.divisor = s->sl_divisor.ptr;
     S.bounce_pd = s->sl_bounce_pd.ptr;
     S.path_length = s->sl_path_length.ptr;
-    S.nee_mask = s->sl_nee_mask.ptr;
     S.nee = reinterpret_cast<float4 *>(s->sl_nee.ptr);
     S.est = s->sl_est.ptr;
     S.cand = s->sl_cand.ptr;

@@ -43,7 +43,6 @@ struct PtSlots {
     double *divisor;       // sample_divisor (worker.cpp:39)
     double *bounce_pd;     // sample_bounce_pd (worker.cpp:40)
     int32_t *path_length;  // worker.cpp:43
-    uint32_t *nee_mask;    // bit j: light sample j of the last vertex contributes if its shadow ray is unoccluded
     float4 *nee;           // [PT_MAX_NEE][total] weighed_spectrum of the pending shadow rays (worker.cpp:97)
     PtEstimator *est;      // per-pixel estimator (worker.cpp:172-192)
     PtCandidate *cand;     // [total][PT_MAX_CANDIDATES]

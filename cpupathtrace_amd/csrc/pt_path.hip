@@ -267,9 +267,11 @@ struct Tracer {
 // ---- the per-slot word in LDS ---------------------------------------------------------------------------------------------------------
 // bits 0..7   visibility of the last vertex's light samples (1 = unoccluded), set by the lanes that finish the shadow rays
 // bits 8..15  rays of the slot still in the queue or being walked
-// bits 16..   PT_F_* flags of the slot
+// bits 16..23 PT_F_* flags of the slot
+// bits 24..31 light samples of the last vertex whose contribution waits in S.nee for its shadow ray (or needed none)
 #define PT_W_PENDING(word) (((word) >> 8) & 0xffu)
-#define PT_W_FLAGS(word) ((word) >> 16)
+#define PT_W_FLAGS(word) (((word) >> 16) & 0xffu)
+#define PT_W_NEE(word) ((word) >> 24)
 #define PT_W_ONE_RAY 0x100u
 
 #define PT_DEST_SLOT_MASK 0xffffu
@@ -399,7 +401,16 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
             // state, and -- a single word, to bring the line into the caches -- the shading record of the triangle that was hit, which
             // is the one access of this pass that usually comes from HBM.
             const float4 out4 = S.out[p];
-            uint32_t mask = S.nee_mask[p];
+            uint32_t mask = PT_W_NEE(word);
+            // the first two light samples (most scenes have no more) are fetched with the batch, the others one by one below
+            const uint32_t lit = mask & vis_bits;
+            float4 nee0 = make_float4(0, 0, 0, 0), nee1 = make_float4(0, 0, 0, 0);
+            if(lit & 1u) {
+                nee0 = S.nee[p];
+            }
+            if(lit & 2u) {
+                nee1 = S.nee[S.total + p];
+            }
             const float4 o4 = S.ray_o[p], d4 = S.ray_d[p], spectrum4 = S.spectrum[p];
             const double divisor_in = S.divisor[p], bounce_pd_in = S.bounce_pd[p];
             const int path_length_in = S.path_length[p];
@@ -414,7 +425,14 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
             }
             out = c4(out4);
             // shadow rays of the previous vertex, in light order (worker.cpp:76-103)
-            for(uint32_t j = 0; mask != 0; j++, mask >>= 1) {
+            if(lit & 1u) {
+                out = out + c4(nee0);
+            }
+            if(lit & 2u) {
+                out = out + c4(nee1);
+            }
+            mask >>= 2;
+            for(uint32_t j = 2; mask != 0; j++, mask >>= 1) {
                 if((mask & 1u) && ((vis_bits >> j) & 1u)) {
                     out = out + c4(S.nee[(size_t)j * S.total + p]);
                 }
@@ -724,7 +742,7 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
         n_rays++;
     }
     if(alive) {
-        word_l[ls] = (flags << 16) | (n_rays << 8) | vis_init;
+        word_l[ls] = (nee_out_mask << 24) | (flags << 16) | (n_rays << 8) | vis_init;
         S.rng[p] = rng;
         S.cursor[p] = cursor;
         if(flags & PT_F_IN_FLIGHT) {
@@ -735,7 +753,6 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
             S.divisor[p] = divisor;
             S.bounce_pd[p] = bounce_pd;
             S.path_length[p] = path_length;
-            S.nee_mask[p] = nee_out_mask;
         }
     }
 }

@@ -927,6 +927,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     dev.n_spheres = d->n_spheres;
     dev.n_lights = d->n_point_lights;
     dev.n_emis = s->n_emissive;
+    dev.n_materials = d->n_materials;
     dev.n_object_samples = static_cast<uint32_t>(object_sample_count);
     // LDS staging: a scene whose whole tree and triangle records fit in 24 KiB lives in LDS entirely (the path kernel's IN_LDS
     // variant); an LDS copy of only the top of a larger tree was measured in round 1 and does not pay.

@@ -254,7 +254,15 @@ struct Material {
     int one_way;
 };
 
-PT_D Material material_load(const float4 *materials, uint32_t idx) {
+// 16 bytes through a pointer of any address space (float4 in global memory, a 4-float vector in LDS)
+template<typename F4Ptr>
+PT_D float4 ldq(F4Ptr p, size_t i) {
+    const auto v = p[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+template<typename F4Ptr>
+PT_D Material material_load(F4Ptr materials, uint32_t idx) {
     Material m;
     if(idx == 0xFFFFFFFFu) {
         // default handler: white Lambertian, no emission (object.cpp:9-11, material.cpp:3-17)
@@ -266,11 +274,11 @@ PT_D Material material_load(const float4 *materials, uint32_t idx) {
         m.one_way = 0;
         return m;
     }
-    const float4 *p = materials + 4 * (size_t)idx;
-    m.diffuse = c4(p[0]);
-    m.specular = c4(p[1]);
-    m.emission = c4(p[2]);
-    float4 q = p[3];
+    const F4Ptr p = materials + 4 * (size_t)idx;
+    m.diffuse = c4(ldq(p, 0));
+    m.specular = c4(ldq(p, 1));
+    m.emission = c4(ldq(p, 2));
+    float4 q = ldq(p, 3);
     m.ior = q.x;
     m.bsdf = (int)__float_as_uint(q.y);
     m.one_way = (int)__float_as_uint(q.z);
@@ -466,6 +474,15 @@ PT_D Ray camera_shoot(const PtDevCamera &cam, float x, float y, float pixel_widt
 
 // ---- surface normal of a hit object -------------------------------------------------------------------------------------
 
+// normal of a triangle from its shading record (six quarters), Triangle::getNormal (object.cpp:126-182)
+template<typename F4Ptr>
+PT_D V3 tri_shade_normal(F4Ptr rec, V3 pos, uint32_t &material) {
+    const TriRec t = tri_unpack(ldq(rec, 0), ldq(rec, 1), ldq(rec, 2));
+    const float4 n0 = ldq(rec, 3), n1 = ldq(rec, 4), n2 = ldq(rec, 5);
+    material = t.material;
+    return tri_normal(t.a, t.ab, t.ac, v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), v3(n1.z, n1.w, n2.x), pos);
+}
+
 PT_D V3 object_normal(const PtDevScene &sc, uint32_t ref, V3 pos, uint32_t &material) {
     uint32_t idx = ref & PT_REF_INDEX;
     if(ref & PT_REF_SPHERE) {
@@ -473,11 +490,7 @@ PT_D V3 object_normal(const PtDevScene &sc, uint32_t ref, V3 pos, uint32_t &mate
         material = sc.sph_meta[idx].x;
         return normalize(pos - v3(s.x, s.y, s.z)); // object.cpp:86-88
     }
-    const float4 *rec = sc.tri_shade + 8 * (size_t)idx; // one 128-byte line: geometry words, then the vertex normals
-    const TriRec t = tri_unpack(rec[0], rec[1], rec[2]);
-    const float4 n0 = rec[3], n1 = rec[4], n2 = rec[5];
-    material = t.material;
-    return tri_normal(t.a, t.ab, t.ac, v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), v3(n1.z, n1.w, n2.x), pos);
+    return tri_shade_normal(sc.tri_shade + 8 * (size_t)idx, pos, material); // one 128-byte line: geometry words, then the vertex normals
 }
 
 } // namespace ptd

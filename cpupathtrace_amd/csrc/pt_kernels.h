@@ -24,6 +24,10 @@
 // and tracing the rays that produced -- without ever synchronising with another wavefront.  A slot that has finished its stream pulls
 // the next one from a global counter.
 
+// Small tables the shading pass reads per lane live in LDS when they have at most PT_LDS_TABLE_MAX entries: the emitters' CDF (4 B),
+// sampling records (64 B) and shading records (96 B: the vertex normals of an emissive triangle), and the materials (64 B).
+#define PT_LDS_TABLE_MAX 16
+#define PT_LDS_TABLE_BYTES (PT_LDS_TABLE_MAX * (4 + 64 + 96 + 64))
 #define PT_WALK_SAVE_WORDS 17
 #define PT_MAX_ROWS 8      /* rows of 64 slots per wavefront */
 #define PT_F_STREAM 128u   /* the slot holds a stream (flag bit, next to PT_F_*) */

@@ -306,6 +306,24 @@ PT_D void tile_stream(const PtStreams &T, uint32_t i, int4 &rect, uint64_t &rng,
     tile = lo;
 }
 
+// The small tables of the shading pass in LDS (PT_LDS_TABLE_MAX entries at most each; larger ones are read from global memory)
+struct EmisLds {
+    const float __attribute__((address_space(3))) *cdf_l;
+    lds_f4_cptr rec_l;   // [4 * n_emis]
+    lds_f4_cptr light_l; // [6 * n_emis]: the shading record of an emissive triangle (unused for spheres)
+    PT_D float cdf(int i) const { return cdf_l[i]; }
+    PT_D float4 rec(int i, int k) const { return to_f4(rec_l[4 * i + k]); }
+    PT_D V3 tri_normal_at(int i, uint32_t, V3 pos) const {
+        uint32_t mat_unused;
+        return tri_shade_normal(light_l + 6 * i, pos, mat_unused);
+    }
+};
+struct ShadeTables {
+    EmisLds emis;
+    lds_f4_cptr materials_l;
+    bool emis_in_lds, materials_in_lds;
+};
+
 // One shading pass over row `row` of the wave's slots: the state machine of one stream per lane.
 //   * a slot without a stream takes the next one from the global counter (or dies when there is none left);
 //   * a slot whose rays have all come back first adds the unoccluded light samples of its previous vertex to out_spectrum in the
@@ -320,7 +338,7 @@ PT_D void tile_stream(const PtStreams &T, uint32_t i, int4 &rect, uint64_t &rng,
 // give every lane its position; rays of one kind from neighbouring pixels end up in neighbouring lanes of the traversal).
 PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOptions &opt, const PtSlots &S, const PtStreams &T, const PtLocalQueue &Q,
                     WaveCtx &ctx, uint32_t row, uint32_t lane, size_t slot_base, size_t queue_base, lds_u32_ptr word_l, lds_u2_ptr hit_l,
-                    float4 *__restrict__ image, PtDevCounters *counters, uint32_t &n_samples, uint32_t &n_vertices) {
+                    float4 *__restrict__ image, PtDevCounters *counters, const ShadeTables &tb, uint32_t &n_samples, uint32_t &n_vertices) {
     const uint32_t ls = row * 64 + lane; // slot of the wave
     const size_t p = slot_base + ls;     // slot of the grid
     const unsigned long long lt = (1ULL << lane) - 1ULL;
@@ -593,7 +611,7 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
         pos = ro + rd * hit_t;
         uint32_t material_index;
         n = object_normal(sc, hit_ref, pos, material_index);
-        mat = material_load(sc.materials, material_index);
+        mat = tb.materials_in_lds ? material_load(tb.materials_l, material_index) : material_load(sc.materials, material_index);
 
         out = out + (spectrum * mat.emission) / (float)(divisor * bounce_pd);
 
@@ -637,7 +655,8 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
                 valid = true;
             }
             else {
-                valid = sample_emissive(sc, pos, rng, light_pos, light_spectrum, lpd);
+                valid = tb.emis_in_lds ? sample_emissive(sc, tb.emis, pos, rng, light_pos, light_spectrum, lpd)
+                                       : sample_emissive(sc, EmisGlobal{sc}, pos, rng, light_pos, light_spectrum, lpd);
             }
             if(valid && want_nee) {
                 const V3 to_light = light_pos - pos;
@@ -781,7 +800,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     }
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // LDS of the workgroup: traversal stacks [STACK_LDS][256] | hit records [4 waves][rows * 64] | slot words [4 waves][rows * 64] |
-    // (small scenes) the whole tree and all triangle records
+    // emitter and material tables (PT_LDS_TABLE_BYTES) | (small scenes) the whole tree and all triangle records
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
     const uint32_t wave_in_block = (uint32_t)tid >> 6;
@@ -794,8 +813,47 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     at += (size_t)4 * n_slots * sizeof(uint2);
     lds_u32_ptr word_l = (lds_u32_ptr)reinterpret_cast<uint32_t *>(at) + wave_in_block * n_slots;
     at += (size_t)4 * n_slots * sizeof(uint32_t);
+    float *cdf_l = reinterpret_cast<float *>(at);
+    at += (size_t)PT_LDS_TABLE_MAX * sizeof(float);
+    float4 *emis_l = reinterpret_cast<float4 *>(at);
+    at += (size_t)PT_LDS_TABLE_MAX * 4 * sizeof(float4);
+    float4 *light_l = reinterpret_cast<float4 *>(at);
+    at += (size_t)PT_LDS_TABLE_MAX * 6 * sizeof(float4);
+    float4 *materials_l = reinterpret_cast<float4 *>(at);
+    at += (size_t)PT_LDS_TABLE_MAX * 4 * sizeof(float4);
     float4 *lds_pairs = reinterpret_cast<float4 *>(at);
     float4 *lds_tris = lds_pairs + 4 * (size_t)A->sc.n_lds_pairs;
+
+    ShadeTables tb;
+    tb.emis.cdf_l = (const float __attribute__((address_space(3))) *)cdf_l;
+    tb.emis.rec_l = (lds_f4_cptr)emis_l;
+    tb.emis.light_l = (lds_f4_cptr)light_l;
+    tb.materials_l = (lds_f4_cptr)materials_l;
+    {
+        const uint32_t n_emis = A->sc.n_emis, n_materials = A->sc.n_materials;
+        tb.emis_in_lds = n_emis > 0 && n_emis <= PT_LDS_TABLE_MAX;
+        tb.materials_in_lds = n_materials > 0 && n_materials <= PT_LDS_TABLE_MAX;
+        if(tb.emis_in_lds) {
+            const float4 *src_emis = A->sc.emis, *src_shade = A->sc.tri_shade;
+            const float *src_cdf = A->sc.emis_cdf;
+            for(uint32_t i = tid; i < n_emis; i += 256) {
+                cdf_l[i] = src_cdf[i];
+            }
+            for(uint32_t i = tid; i < 4 * n_emis; i += 256) {
+                emis_l[i] = src_emis[i];
+            }
+            for(uint32_t i = tid; i < 6 * n_emis; i += 256) {
+                const uint32_t ref = __float_as_uint(src_emis[4 * (i / 6) + 2].y);
+                light_l[i] = (ref & PT_REF_SPHERE) ? make_float4(0, 0, 0, 0) : src_shade[8 * (size_t)(ref & PT_REF_INDEX) + i % 6];
+            }
+        }
+        if(tb.materials_in_lds) {
+            const float4 *src_materials = A->sc.materials;
+            for(uint32_t i = tid; i < 4 * n_materials; i += 256) {
+                materials_l[i] = src_materials[i];
+            }
+        }
+    }
 
     if(IN_LDS) {
         const uint32_t n_lds_pairs = A->sc.n_lds_pairs, n_lds_tris = A->sc.n_lds_tris;
@@ -900,7 +958,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
             }
 #pragma unroll 1
             for(uint32_t r = 0; r < (uint32_t)rows; r++) {
-                shade_row(P->sc, P->cam, P->opt, P->S, P->T, P->Q, ctx, r, lane, slot_base, queue_base, word_l, hit_l, P->image, P->counters, n_samples, n_vertices);
+                shade_row(P->sc, P->cam, P->opt, P->S, P->T, P->Q, ctx, r, lane, slot_base, queue_base, word_l, hit_l, P->image, P->counters, tb, n_samples, n_vertices);
             }
             // the rays just written are read back by other lanes of this wavefront
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1329,7 +1387,7 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
 
 size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_tris) {
     const size_t scene = (n_lds_pairs != 0 || n_lds_tris != 0) ? (size_t)n_lds_pairs * 64 + (size_t)n_lds_tris * 48 + 16 : 0;
-    return (size_t)stack_lds * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + sizeof(uint32_t)) + scene;
+    return (size_t)stack_lds * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + sizeof(uint32_t)) + PT_LDS_TABLE_BYTES + scene;
 }
 
 int pt_path_blocks_per_cu(int stack_lds, int in_lds, size_t lds_bytes) {

@@ -207,13 +207,25 @@ PT_D void estimator_reset(PtEstimator &e, const PtDevOptions &opt) {
 
 // ---- Scene::sampleLights, one light sample (scene.cpp:238-286) ----------------------------------------------------------
 // Draws 3 numbers; returns false when the reference `continue`s.
-PT_D bool sample_emissive(const PtDevScene &sc, V3 pos, uint64_t &rng, V3 &light_pos, C4 &spectrum, float &pd) {
+// The emitter tables as they lie in global memory ...
+struct EmisGlobal {
+    const PtDevScene &sc;
+    PT_D float cdf(int i) const { return sc.emis_cdf[i]; }
+    PT_D float4 rec(int i, int k) const { return sc.emis[4 * (size_t)i + k]; }
+    PT_D V3 tri_normal_at(int, uint32_t ref, V3 pos) const {
+        uint32_t mat_unused;
+        return object_normal(sc, ref, pos, mat_unused);
+    }
+};
+
+template<typename Tables>
+PT_D bool sample_emissive(const PtDevScene &sc, const Tables &tb, V3 pos, uint64_t &rng, V3 &light_pos, C4 &spectrum, float &pd) {
     const float r = rng_uniform01(rng);
     // std::lower_bound over the CDF
     int lo = 0, n = (int)sc.n_emis;
     while(n > 0) {
         const int half = n >> 1;
-        if(sc.emis_cdf[lo + half] < r) {
+        if(tb.cdf(lo + half) < r) {
             lo = lo + half + 1;
             n = n - half - 1;
         }
@@ -222,14 +234,13 @@ PT_D bool sample_emissive(const PtDevScene &sc, V3 pos, uint64_t &rng, V3 &light
         }
     }
     const int object_index = lo;
-    float selection_p = sc.emis_cdf[object_index];
+    float selection_p = tb.cdf(object_index);
     if(object_index > 0) {
-        selection_p -= sc.emis_cdf[object_index - 1];
+        selection_p -= tb.cdf(object_index - 1);
     }
     selection_p *= (float)sc.n_object_samples;
 
-    const float4 *rec = sc.emis + 4 * (size_t)object_index;
-    const float4 e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3];
+    const float4 e0 = tb.rec(object_index, 0), e1 = tb.rec(object_index, 1), e2 = tb.rec(object_index, 2), e3 = tb.rec(object_index, 3);
     const uint32_t ref = __float_as_uint(e2.y);
     V3 surface_pos, surface_n;
     float surface_p;
@@ -259,8 +270,7 @@ PT_D bool sample_emissive(const PtDevScene &sc, V3 pos, uint64_t &rng, V3 &light
         const float area = len(cross(b - a, c - a)) / 2.0f;
         surface_p = 1.0f / area;
         surface_cull = __float_as_uint(e2.z) != 0;
-        uint32_t mat_unused;
-        surface_n = object_normal(sc, ref, surface_pos, mat_unused);
+        surface_n = tb.tri_normal_at(object_index, ref, surface_pos);
     }
 
     const V3 to_light = surface_pos - pos;

@@ -56,6 +56,7 @@ struct PtDevScene {
     uint32_t n_spheres;
     uint32_t n_lights;
     uint32_t n_emis;
+    uint32_t n_materials;
     uint32_t n_object_samples; /* min(2 + int(log10(E + 1)), E), scene.cpp:226 */
     uint32_t n_lds_pairs;      /* small scenes: all pair records are staged in LDS by the path kernel (else 0) */
     uint32_t n_lds_tris;       /* small scenes: all triangle records are staged in LDS (else 0) */

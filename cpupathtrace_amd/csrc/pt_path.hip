@@ -908,6 +908,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     w.occluded = false;
     typename Tracer<STACK_LDS, IN_LDS>::Rec rec;
     rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    float4 win_o = make_float4(0, 0, 0, 0), win_d = make_float4(0, 0, 0, __uint_as_float(PT_DEST_NULL)); // the lane's ray of the ring's window
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0, n_samples = 0, n_vertices = 0;
     uint32_t w_steps = 0, w_passes = 0; // wave-level diagnostics (same value in every lane)
 #ifdef PT_PATH_TIMING
@@ -986,6 +987,15 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
 #ifdef PT_PATH_TIMING
             t_shade += __builtin_amdgcn_s_memtime() - t_pass;
 #endif
+            // the ring has new rays: its first 64 go to the lanes' window registers (which did not live across the pass)
+            win_o = make_float4(0, 0, 0, 0);
+            win_d = make_float4(0, 0, 0, __uint_as_float(PT_DEST_NULL));
+            if(lane < ctx.q_count) {
+                uint32_t i = ctx.q_head + lane;
+                i = i >= Q.cap ? i - Q.cap : i;
+                win_o = Q.ray_o[queue_base + i];
+                win_d = Q.ray_d[queue_base + i];
+            }
             // the record registers do not live across a shading pass: walks in progress fetch theirs again
             rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
             if(active && w.cur != PT_REF_NONE) {
@@ -1028,25 +1038,29 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                     }
                 }
                 if(ctx.q_count > 0) {
+                    // The ring's next 64 rays are already in registers, one per lane (requested when the ring's head last moved:
+                    // reading them here would stall the whole wavefront, walks in progress included, for a memory round trip); an
+                    // idle lane takes the ray of the lane whose number is its rank among the idle ones.
                     const uint32_t take = ctx.q_count < n_idle ? ctx.q_count : n_idle;
-                    if(!active) {
-                        const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
-                        if(rank < take) {
-                            uint32_t i = ctx.q_head + rank;
-                            i = i >= Q.cap ? i - Q.cap : i;
-                            const float4 ro = Q.ray_o[queue_base + i];
-                            const float4 rd = Q.ray_d[queue_base + i];
-                            if(__float_as_uint(rd.w) != PT_DEST_NULL) {
-                                tr.start(w, rec, root, ro, rd);
-                                active = true;
-                                n_rays++;
-                                n_shadow += (w.dest & PT_DEST_SHADOW) ? 1u : 0u;
-                            }
-                        }
+                    const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
+                    const int src = (int)(rank & 63u);
+                    const float4 ro = make_float4(__shfl(win_o.x, src), __shfl(win_o.y, src), __shfl(win_o.z, src), __shfl(win_o.w, src));
+                    const float4 rd = make_float4(__shfl(win_d.x, src), __shfl(win_d.y, src), __shfl(win_d.z, src), __shfl(win_d.w, src));
+                    if(!active && rank < take && __float_as_uint(rd.w) != PT_DEST_NULL) {
+                        tr.start(w, rec, root, ro, rd);
+                        active = true;
+                        n_rays++;
+                        n_shadow += (w.dest & PT_DEST_SHADOW) ? 1u : 0u;
                     }
                     ctx.q_head += take;
                     ctx.q_head = ctx.q_head >= Q.cap ? ctx.q_head - Q.cap : ctx.q_head;
                     ctx.q_count -= take;
+                    if(lane < ctx.q_count) {
+                        uint32_t i = ctx.q_head + lane;
+                        i = i >= Q.cap ? i - Q.cap : i;
+                        win_o = Q.ray_o[queue_base + i];
+                        win_d = Q.ray_d[queue_base + i];
+                    }
                 }
             }
             if(__ballot(active) == 0ULL) {

@@ -164,9 +164,14 @@ struct Tracer {
         w.inv = slab_inverse(w.d);
         w.best_ref = PT_REF_NONE;
         w.best_t = -1.0f;
-        // a shadow ray only asks for a hit nearer than the light: nothing that is entered at or beyond that distance can hold one,
-        // so the walk starts with the threshold as its pruning distance
-        w.t_max = (w.dest & PT_DEST_SHADOW) ? w.thr : FLT_MAX;
+        // A shadow ray is a closest-hit query like any other in the reference (worker.cpp:83-86) and must be pruned like one: starting it
+        // with the light's distance as pruning distance is NOT the same thing in floating point.  The sampled point lies on an emitter,
+        // the ray starts epsilon in front of the vertex and the threshold is |to_light| - epsilon: the emitter's own hit distance and
+        // the threshold are the same number up to rounding, and the reference finds "occluded" whenever the hit comes out an ulp
+        // below.  A box around a flat, axis-aligned emitter is entered at that very distance (again up to rounding, of the slab test
+        // this time), so pruning at the threshold skipped the emitter in cases where the reference tested it and found t < threshold.
+        // The walk still ends at the first hit below the threshold (the closest hit can only be nearer).
+        w.t_max = FLT_MAX;
         w.sp = 0;
         w.occluded = false;
         w.cur = PT_REF_NONE;

@@ -173,6 +173,25 @@ def _tie_heavy_scene():
     return sb.build()
 
 
+def _many_materials_scene():
+    """24 materials (more than the path kernel keeps in LDS: the material table is read from global memory) of all three BSDF kinds on
+    a wall of small quads, lit by an emissive quad and an emissive sphere (3 emitters: the emitter tables ARE in LDS)."""
+    sb = scenes.SceneBuilder()
+    sb.triangles(scenes.make_box((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), sb.material((0.8, 0.8, 0.8, 1.0)))
+    lit = sb.material((1, 1, 1, 1), 1.0, (3, 2.5, 2, 1))
+    sb.triangles(scenes.make_plane((-0.3, 0.95, -0.3), (0.3, 0.95, 0.3)), lit)
+    sb.sphere((-0.6, 0.5, -0.5), 0.12, sb.material((1, 1, 1, 1), 1.0, (1, 2, 4, 1)))
+    rng = np.random.default_rng(5)
+    for k in range(21):
+        kind = (scenes.BSDF_LAMBERTIAN, scenes.BSDF_GLASS, scenes.BSDF_MIRROR)[k % 3]
+        colour = tuple(float(v) for v in rng.uniform(0.2, 1.0, 3)) + (1.0,)
+        m = sb.material(colour, 1.0 + 0.05 * k, bsdf=kind, specular=tuple(float(v) for v in rng.uniform(0.5, 1.0, 3)) + (1.0,))
+        x, y = -0.9 + 0.25 * (k % 7), -0.8 + 0.45 * (k // 7)
+        z = 0.3 + 0.02 * k
+        sb.triangles([[(x, y, z), (x + 0.22, y, z + 0.05), (x, y + 0.4, z)], [(x + 0.22, y, z + 0.05), (x + 0.22, y + 0.4, z + 0.05), (x, y + 0.4, z)]], m)
+    return sb.build()
+
+
 @pytest.mark.parametrize("name", SCENES + ["dragons16", "ties", "ties_face_normals"])
 def test_device_build_matches_host_build(sset, oracle_lib, name):
     """the tree built level by level on the device (pt_build.hip) against the host recursion (pt_bvh.cpp) and the
@@ -498,9 +517,11 @@ def test_frame_identical_for_any_gpu_count(gpu_scenes, sset, world, side):
     ("advanced", 16, 9, 8, 8, 1e-2),        # large epsilon: shadow thresholds below zero, self-intersection offsets
     ("box", 11, 13, 8, 8, 1e-6),            # tiny epsilon
     ("ties", 12, 12, 6, 6, 1e-3),           # 1031 emissive objects: 5 object samples per vertex, duplicated triangles
+    ("many_materials", 24, 20, 12, 12, 1e-3),  # 24 materials (table in global memory), 3 emitters incl. a sphere (tables in LDS)
 ])
 def test_unusual_options_vs_oracle(sset, oracle_lib, name, w, h, mn, mx, eps):
-    desc, cam = (_tie_heavy_scene(), scenes.camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, -1.0)) if name == "ties" else sset[name]
+    default_cam = scenes.camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, -1.0)
+    desc, cam = (_tie_heavy_scene(), default_cam) if name == "ties" else (_many_materials_scene(), default_cam) if name == "many_materials" else sset[name]
     opt = scenes.options(w, h, mn, mx, eps)
     scene = binding.Scene(desc)
     try:

@@ -1,6 +1,7 @@
 """Differential test: random scenes (triangles and spheres at inexact coordinates, all BSDF kinds, emitters of both kinds, point lights,
 all aperture kinds, with and without a surrounding box) rendered by the HIP path and by the CPU oracle, pixel for pixel and engine
-state for engine state.       python tools/parity_fuzz.py [first_seed] [n_scenes] [width] [height] [spp]"""
+state for engine state.       python tools/parity_fuzz.py [first_seed] [n_scenes] [width] [height] [spp_min] [spp_max] [tri_scale]
+(PT_LDS_SMALL=0 in the environment keeps small trees in HBM: the other variant of the kernel)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +9,7 @@ import oracle
 from cpupathtrace_amd import binding, scenes
 
 
-def random_scene(seed):
+def random_scene(seed, tri_scale=1):
     rng = np.random.default_rng(seed)
     sb = scenes.SceneBuilder()
     u = lambda lo, hi, n=None: rng.uniform(lo, hi, n)
@@ -33,7 +34,7 @@ def random_scene(seed):
             continue
         if len(np.asarray(quad).reshape(-1)) > 0:
             sb.triangles(quad, pick(), cull=bool(rng.random() < 0.3))
-    n_tri = int(rng.integers(0, 60))
+    n_tri = int(rng.integers(0, 60 * tri_scale))
     if n_tri:
         base = u(-0.9, 0.9, (n_tri, 1, 3))
         tri = (base + u(-0.35, 0.35, (n_tri, 3, 3))).astype(np.float32)
@@ -60,13 +61,15 @@ def main():
     w = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     h = int(sys.argv[4]) if len(sys.argv) > 4 else 16
     spp = int(sys.argv[5]) if len(sys.argv) > 5 else 6
+    spp_max = int(sys.argv[6]) if len(sys.argv) > 6 else spp
+    tri_scale = int(sys.argv[7]) if len(sys.argv) > 7 else 1
     ol = oracle.Checker("oracle")
     ys, xs = np.mgrid[0:h, 0:w]
     xs, ys = xs.ravel().astype(np.int32), ys.ravel().astype(np.int32)
     failures = 0
     for seed in range(first, first + n):
-        desc, cam = random_scene(seed)
-        opt = scenes.options(w, h, spp, spp, float(np.random.default_rng(seed + 7).choice([1e-3, 1e-4, 1e-2])))
+        desc, cam = random_scene(seed, tri_scale)
+        opt = scenes.options(w, h, spp, spp_max, float(np.random.default_rng(seed + 7).choice([1e-3, 1e-4, 1e-2])))
         states = np.array([binding.seed_to_state(binding.pixel_seed(1000 + seed, int(x), int(y))) for x, y in zip(xs, ys)], np.uint64)
         try:
             s = binding.Scene(desc)

@@ -77,8 +77,24 @@ def main():
             print("seed %d: scene refused (%s)" % (seed, e), flush=True)
             continue
         img, after = s.process_item(cam, opt, binding.pixel_streams(xs, ys, states))
+        # the tree (both builders for scenes the device builder takes) and closest hits on random rays
+        ho = ol.scene_create(desc)
+        rr = np.random.default_rng(seed + 99)
+        d3 = rr.normal(size=(4000, 3)); d3 /= np.linalg.norm(d3, axis=1, keepdims=True)
+        rays = np.concatenate([rr.uniform(-1.2, 1.2, (4000, 3)), d3], axis=1).astype(np.float32)
+        t_g, o_g = s.get_intersection(rays)
+        t_o, o_o = ho.intersect(rays)
+        hit = t_o >= 0
+        tree_g, box_g = s.bvh_dump()
+        tree_o, box_o = ol.bvh_dump(desc)
         s.close()
-        want, want_after = ol.scene_create(desc).render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=8)
+        if not (np.array_equal(tree_g, tree_o) and np.array_equal(box_g.view(np.uint32), box_o.view(np.uint32))):
+            failures += 1
+            print("seed %d: BVH differs from the oracle's" % seed, flush=True)
+        if not (np.array_equal(t_g.view(np.uint32)[hit], t_o.view(np.uint32)[hit]) and np.array_equal(o_g[hit], o_o[hit]) and (t_g[~hit] < 0).all()):
+            failures += 1
+            print("seed %d: closest hits differ for %d of %d rays" % (seed, int(((t_g.view(np.uint32) != t_o.view(np.uint32)) & hit).sum() + ((t_g >= 0) & ~hit).sum()), len(rays)), flush=True)
+        want, want_after = ho.render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=8)
         g, wv = np.ascontiguousarray(img).reshape(-1, 4), want.reshape(-1, 4)
         both_nan = np.isnan(g) & np.isnan(wv)
         bad = ((g.view(np.uint32) != wv.view(np.uint32)) & ~both_nan).any(axis=1)

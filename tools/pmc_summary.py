@@ -15,3 +15,27 @@ for k in agg:
     print("==", k)
     for c in sorted(agg[k]):
         print("  %-40s total %.6g  per-dispatch %.6g  (n=%d)" % (c, agg[k][c], agg[k][c] / cnt[k][c], cnt[k][c]))
+
+# derived figures (gfx950: 8 XCDs, 256 CUs, 1024 SIMDs; FETCH_SIZE counts 64 B per 128-B request -> 2 x FETCH_SIZE + WRITE_SIZE KiB)
+samples = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+for k in agg:
+    v = {c: agg[k][c] / cnt[k][c] for c in agg[k]}
+    need = ["GRBM_GUI_ACTIVE", "GRBM_TA_BUSY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU", "TCP_TCC_READ_REQ_sum",
+            "TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_GATE_EN1_sum", "FETCH_SIZE", "WRITE_SIZE"]
+    if any(c not in v for c in need):
+        continue
+    dur = v["GRBM_GUI_ACTIVE"] / 8
+    print("# derived, per dispatch of", k)
+    print("#   kernel duration            = GRBM_GUI_ACTIVE / 8 XCDs = %.3g cycles" % dur)
+    print("#   texture addresser busy     = GRBM_TA_BUSY / GRBM_GUI_ACTIVE = %.1f %%;  L1 accesses %.2f per clock per CU" % (100 * v["GRBM_TA_BUSY"] / v["GRBM_GUI_ACTIVE"], v["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256 / dur))
+    print("#   waves waiting              = SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.1f %%   instruction in flight %.1f %%   issue stalls %.1f %%" % (
+        100 * v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 100 * v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"], 100 * v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"]))
+    print("#   VALU busy per SIMD         = SQ_INSTS_VALU * 4 / 1024 SIMDs / duration = %.1f %%" % (100 * v["SQ_INSTS_VALU"] * 4 / 1024 / dur))
+    print("#   L1 (TCP) hit rate          = %.1f %%   L2 (TCC) hit rate = %.1f %%   mean L1-miss latency = %.0f cycles   L1 stalled on pending misses = %.1f %%" % (
+        100 * (1 - v["TCP_TCC_READ_REQ_sum"] / v["TCP_TOTAL_CACHE_ACCESSES_sum"]), 100 * v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]),
+        v["TCP_TCC_READ_REQ_LATENCY_sum"] / v["TCP_TCC_READ_REQ_sum"], 100 * v["TCP_PENDING_STALL_CYCLES_sum"] / v["TCP_GATE_EN1_sum"]))
+    hbm = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+    print("#   HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B) = %.3g B%s" % (hbm, (" = %.0f B per sample (%.3g samples)" % (hbm / samples, samples)) if samples else ""))
+    if samples:
+        print("#   instructions per sample    : VALU %.0f  SALU %.0f  VMEM read %.1f  VMEM write %.1f  LDS %.1f" % (
+            v["SQ_INSTS_VALU"] / samples, v.get("SQ_INSTS_SALU", 0) / samples, v.get("SQ_INSTS_VMEM_RD", 0) / samples, v.get("SQ_INSTS_VMEM_WR", 0) / samples, v.get("SQ_INSTS_LDS", 0) / samples))

@@ -398,6 +398,24 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     Q.ray_d = reinterpret_cast<float4 *>(s->lq_ray_d.ptr);
     Q.cap = s->path_cap;
     T.next = s->pull_counter.ptr;
+    T.first_total = s->path_waves * static_cast<uint32_t>(cfg.slots_per_wave);
+    T.n_waves = s->path_waves;
+    // The first round (pt_path.hip, stream hand-out): piece q of wavefront w -- `first_lanes` neighbouring slots -- starts on the chunk
+    // q * waves + w of as many streams, moved q steps sideways in a regular tile grid.
+    T.first_spread = (cfg.slots_per_wave == cfg.rows * 64 && env_int("PT_FIRST_SPREAD", 1) != 0) ? 1U : 0U;
+    T.first_lanes = static_cast<uint32_t>(env_int("PT_FIRST_LANES", 8)); // measured: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440 Msamples/s on the benchmark frame
+    if(T.first_lanes != 64 && T.first_lanes != 32 && T.first_lanes != 16 && T.first_lanes != 8) {
+        T.first_lanes = 8;
+    }
+    {
+        // the sideways move needs: a regular grid, a first round that does not reach beyond the job and covers whole grid rows per piece,
+        // and as many tiles per grid row as a multiple of the pieces of a wavefront
+        const uint32_t pieces = static_cast<uint32_t>(cfg.rows) * 64U / T.first_lanes;
+        const unsigned long long per_grid_row = static_cast<unsigned long long>(T.chunks_per_tile) * (64U / T.first_lanes) * T.tiles_per_row;
+        if(env_int("PT_FIRST_SPREAD", 1) == 2 || per_grid_row == 0 || s->path_waves % per_grid_row != 0 || T.first_total > T.n || T.tiles_per_row % pieces != 0) {
+            T.tiles_per_row = 0;
+        }
+    }
     T.tile_left = nullptr;
     T.tiles_done = nullptr;
     if(progress != nullptr && T.rect == nullptr && T.n_tiles > 0) {
@@ -1304,6 +1322,30 @@ static int render_tiles_impl(pt_scene *s, const pt_camera_params *camera, const 
         T.tile_offset = s->tile_offset.ptr;
         T.n_tiles = static_cast<uint32_t>(n_tiles);
         T.base_seed = base_seed;
+        // A regular grid of equal tiles (what pt_job_tiles makes of a frame whose sides are multiples of the tile size) lets the kernel
+        // spread a wavefront's first rows over the frame's columns as well as over its bands: tiles per grid row, 64-stream chunks per tile.
+        T.tiles_per_row = 0;
+        T.chunks_per_tile = 0;
+        if(n_tiles > 0 && (static_cast<uint32_t>(tiles[0].w) * static_cast<uint32_t>(tiles[0].h)) % 64U == 0) {
+            bool regular = true;
+            uint32_t per_row = 0;
+            for(size_t k = 0; k < n_tiles && regular; k++) {
+                regular = tiles[k].w == tiles[0].w && tiles[k].h == tiles[0].h;
+                if(per_row == 0 && k > 0 && tiles[k].y != tiles[0].y) {
+                    per_row = static_cast<uint32_t>(k);
+                }
+            }
+            if(per_row == 0) {
+                per_row = static_cast<uint32_t>(n_tiles);
+            }
+            for(size_t k = 0; k < n_tiles && regular; k++) {
+                regular = tiles[k].x == tiles[0].x + static_cast<int32_t>(k % per_row) * tiles[0].w && tiles[k].y == tiles[0].y + static_cast<int32_t>(k / per_row) * tiles[0].h;
+            }
+            if(regular && n_tiles % per_row == 0 && per_row % 4 == 0) {
+                T.tiles_per_row = per_row;
+                T.chunks_per_tile = static_cast<uint32_t>(tiles[0].w) * static_cast<uint32_t>(tiles[0].h) / 64U;
+            }
+        }
         return run_path(s, cam, opt, T, d_image, stats, progress, progress_user);
     }
 }

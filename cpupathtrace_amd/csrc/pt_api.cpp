@@ -404,6 +404,7 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     // q * waves + w of as many streams, moved q steps sideways in a regular tile grid.
     T.first_spread = (cfg.slots_per_wave == cfg.rows * 64 && env_int("PT_FIRST_SPREAD", 1) != 0) ? 1U : 0U;
     T.first_lanes = static_cast<uint32_t>(env_int("PT_FIRST_LANES", 8)); // measured: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440 Msamples/s on the benchmark frame
+    T.first_shift = static_cast<uint32_t>(std::max(env_int("PT_FIRST_SHIFT", 1), 0));
     if(T.first_lanes != 64 && T.first_lanes != 32 && T.first_lanes != 16 && T.first_lanes != 8) {
         T.first_lanes = 8;
     }

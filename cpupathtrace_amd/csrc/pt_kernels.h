@@ -65,6 +65,7 @@ struct PtStreams {
     uint64_t base_seed;
     uint32_t first_total;        // streams 0 .. first_total-1 belong to the wavefronts' slots from the start (wavefront * slots_per_wave + slot)
     uint32_t first_lanes;        // streams per piece of the first round (64 = a row of slots; 32, 16: parts of a row)
+    uint32_t first_shift;        // sideways steps per piece
     uint32_t n_waves, first_spread; // first_spread: row r of wavefront w starts on the 64-stream chunk r * n_waves + w ...
     uint32_t tiles_per_row, chunks_per_tile; // ... moved sideways by r * tiles_per_row / 4 tiles in a regular tile grid (0 = no grid)
     uint32_t *next;              // global pull counter (alone in its cache line)

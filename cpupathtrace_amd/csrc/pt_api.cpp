@@ -405,7 +405,7 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     T.first_spread = (cfg.slots_per_wave == cfg.rows * 64 && env_int("PT_FIRST_SPREAD", 1) != 0) ? 1U : 0U;
     T.first_lanes = static_cast<uint32_t>(env_int("PT_FIRST_LANES", 8)); // measured: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440 Msamples/s on the benchmark frame
     T.first_shift = static_cast<uint32_t>(std::max(env_int("PT_FIRST_SHIFT", 1), 0));
-    if(T.first_lanes != 64 && T.first_lanes != 32 && T.first_lanes != 16 && T.first_lanes != 8) {
+    if(T.first_lanes != 64 && T.first_lanes != 32 && T.first_lanes != 16 && T.first_lanes != 8 && T.first_lanes != 4 && T.first_lanes != 2 && T.first_lanes != 1) {
         T.first_lanes = 8;
     }
     {
@@ -413,7 +413,7 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
         // and as many tiles per grid row as a multiple of the pieces of a wavefront
         const uint32_t pieces = static_cast<uint32_t>(cfg.rows) * 64U / T.first_lanes;
         const unsigned long long per_grid_row = static_cast<unsigned long long>(T.chunks_per_tile) * (64U / T.first_lanes) * T.tiles_per_row;
-        if(env_int("PT_FIRST_SPREAD", 1) == 2 || per_grid_row == 0 || s->path_waves % per_grid_row != 0 || T.first_total > T.n || T.tiles_per_row % pieces != 0) {
+        if(env_int("PT_FIRST_SPREAD", 1) == 2 || per_grid_row == 0 || s->path_waves % per_grid_row != 0 || T.first_total > T.n || (T.tiles_per_row % pieces != 0 && pieces % T.tiles_per_row != 0)) {
             T.tiles_per_row = 0;
         }
     }

@@ -385,7 +385,8 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
                     if(T.tiles_per_row != 0) {
                         const uint32_t per_tile = T.chunks_per_tile * (64u / g), pieces = (T.first_total / T.n_waves) / g;
                         const uint32_t tile = chunk / per_tile, sub = chunk % per_tile;
-                        const uint32_t tx = (tile % T.tiles_per_row + q * T.first_shift * (T.tiles_per_row / pieces)) % T.tiles_per_row, ty = tile / T.tiles_per_row;
+                        const uint32_t step = T.tiles_per_row >= pieces ? T.tiles_per_row / pieces : 1u;
+                        const uint32_t tx = (tile % T.tiles_per_row + q * T.first_shift * step) % T.tiles_per_row, ty = tile / T.tiles_per_row;
                         chunk = (ty * T.tiles_per_row + tx) * per_tile + sub;
                     }
                     base = 0; // (only compared with T.n below)

@@ -322,7 +322,22 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     }
     const uint32_t grid = std::max<uint32_t>(1U, std::min<uint32_t>(max_grid, (waves_wanted + 3U) / 4U));
     const uint32_t waves = grid * 4U;
-    const uint32_t slots_per_wave = std::min<uint32_t>(static_cast<uint32_t>(cfg.rows) * 64U, std::max<uint32_t>(1U, (n + waves - 1U) / waves));
+    uint32_t slots_per_wave = std::min<uint32_t>(static_cast<uint32_t>(cfg.rows) * 64U, std::max<uint32_t>(1U, (n + waves - 1U) / waves));
+    // The first round of streams goes to the slots in pieces of `first_lanes` neighbouring slots (pt_path.hip, stream hand-out): a
+    // wavefront's slots are a whole number of pieces (a large job gets up to 7 more slots per wavefront, a small one pieces of 1).
+    uint32_t first_lanes = static_cast<uint32_t>(env_int("PT_FIRST_LANES", 8)); // measured: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440, 4 -> 431 Msamples/s
+    if(first_lanes == 0 || first_lanes > 64 || (first_lanes & (first_lanes - 1U)) != 0) {
+        first_lanes = 8;
+    }
+    if(slots_per_wave % first_lanes != 0) {
+        if(slots_per_wave >= 64U) {
+            slots_per_wave = (slots_per_wave + first_lanes - 1U) / first_lanes * first_lanes; // (rows * 64 is a multiple of every piece size)
+        }
+        else {
+            first_lanes = 1;
+        }
+    }
+    cfg.first_lanes = static_cast<int>(first_lanes);
     const uint32_t rows = (slots_per_wave + 63U) / 64U;
     const uint32_t total = waves * rows * 64U;
     const uint32_t rays_per_slot = 1U + s->dev.n_lights + s->dev.n_object_samples;
@@ -402,16 +417,13 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     T.n_waves = s->path_waves;
     // The first round (pt_path.hip, stream hand-out): piece q of wavefront w -- `first_lanes` neighbouring slots -- starts on the chunk
     // q * waves + w of as many streams, moved q steps sideways in a regular tile grid.
-    T.first_spread = (cfg.slots_per_wave == cfg.rows * 64 && env_int("PT_FIRST_SPREAD", 1) != 0) ? 1U : 0U;
-    T.first_lanes = static_cast<uint32_t>(env_int("PT_FIRST_LANES", 8)); // measured: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440 Msamples/s on the benchmark frame
+    T.first_spread = env_int("PT_FIRST_SPREAD", 1) != 0 ? 1U : 0U;
+    T.first_lanes = static_cast<uint32_t>(cfg.first_lanes);
     T.first_shift = static_cast<uint32_t>(std::max(env_int("PT_FIRST_SHIFT", 1), 0));
-    if(T.first_lanes != 64 && T.first_lanes != 32 && T.first_lanes != 16 && T.first_lanes != 8 && T.first_lanes != 4 && T.first_lanes != 2 && T.first_lanes != 1) {
-        T.first_lanes = 8;
-    }
     {
         // the sideways move needs: a regular grid, a first round that does not reach beyond the job and covers whole grid rows per piece,
         // and as many tiles per grid row as a multiple of the pieces of a wavefront
-        const uint32_t pieces = static_cast<uint32_t>(cfg.rows) * 64U / T.first_lanes;
+        const uint32_t pieces = static_cast<uint32_t>(cfg.slots_per_wave) / T.first_lanes;
         const unsigned long long per_grid_row = static_cast<unsigned long long>(T.chunks_per_tile) * (64U / T.first_lanes) * T.tiles_per_row;
         if(env_int("PT_FIRST_SPREAD", 1) == 2 || per_grid_row == 0 || s->path_waves % per_grid_row != 0 || T.first_total > T.n || (T.tiles_per_row % pieces != 0 && pieces % T.tiles_per_row != 0)) {
             T.tiles_per_row = 0;

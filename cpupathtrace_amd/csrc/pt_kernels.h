@@ -93,6 +93,7 @@ struct PtPathConfig {
     int refill_idle;      // idle lanes that make a wavefront refill from its queue (or shade when the queue is empty)
     int min_ready;        // slots that must be ready before a wavefront with walks in progress stops tracing to shade
     int burst_steps;      // traversal steps between two looks at the queue
+    int first_lanes;      // slots per piece of the first round of streams (slots_per_wave is a multiple of it)
     int leaf_min;         // lanes that must stand on a leaf before the leaf code runs (while other lanes still have nodes to visit)
     unsigned long long *wave_counters; // [grid * 4 waves][8] node visits, leaf tests, rays, shadow rays, wave steps, shading passes, samples, vertices
 };

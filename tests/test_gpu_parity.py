@@ -392,6 +392,20 @@ def _check_frame_against_oracle(scene, handle, cam, opt, seed, n_pixels=3000, qu
     return frame
 
 
+@pytest.mark.parametrize("w,h", [(700, 700), (1000, 1000), (1448, 1448), (1031, 517)])
+def test_frame_sizes_between_the_grid_steps(sset, oracle_lib, w, h):
+    """Frames that do not fill the wavefronts' slots evenly (the first round of streams rounds a wavefront's slots up to whole pieces, or
+    hands out more streams than slots: DESIGN.md 4), with tiles cut at the frame's edges: sampled against the oracle."""
+    desc, cam = sset["cornell"]
+    scene = binding.Scene(desc)
+    handle = oracle_lib.scene_create(desc)
+    try:
+        _check_frame_against_oracle(scene, handle, cam, scenes.options(w, h, 3, 3), seed=77, n_pixels=1500, quadrants=False)
+    finally:
+        scene.close()
+        handle.close()
+
+
 @pytest.mark.parametrize("which,spp_min,spp_max", [("cornell", 16, 16), ("mesh80k", 8, 8), ("cornell_adaptive", 4, 24), ("dragons16_180k", 8, 8)])
 def test_full_size_frame_sampled_against_oracle(sset, oracle_lib, which, spp_min, spp_max):
     """BASELINE.json's frame size (1024 x 1024, one stream per pixel = 1 M streams in flight) checked where the oracle can follow.

@@ -10,16 +10,19 @@ shadow rays.  A "step" is one whole processJob of the workload's frame.  Default
 DragonBox scene (benchmark/main.cpp:59-105) with the procedural 7.2 M-triangle stand-in for assets/xyzrgb_dragon.obj
 (absent from the reference mount), 1024 x 1024, 1024 spp.
 
-N > 1.  One process per GPU over RCCL.  Started either by the launcher (`python -m torch.distributed.run --nproc-per-node N
+N > 1 renders the SAME frame (strong scaling: the metric is quoted on one frame, BASELINE.json) unless --scaling weak is given, and then
+adds one step of the weak-scaling frame (sqrt(N) times the resolution per side) under "weak" in the JSON line.  One process per GPU over RCCL.  Started either by the launcher (`python -m torch.distributed.run --nproc-per-node N
 bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE come from the environment) or directly (`python bench.py --gpus N`):
 then this process starts the N ranks itself as child processes BEFORE anything touches a GPU, hands them RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_ADDR / MASTER_PORT, passes rank 0's JSON line through and exits non-zero if any rank fails.  The tiles of the
 frame (reference src/worker.cpp:398-414) are interleaved over the ranks, the scene is replicated, and the finished tiles are
 gathered to rank 0 over RCCL at the end of every step (the multi-GPU form of doWorkParallel, src/worker.cpp:364-387).
-  --scaling weak   (default) the same view at sqrt(N) times the resolution per side (1448, 2048, 2896 pixels for 2, 4, 8 GPUs):
-                   every GPU renders `size`^2 pixels of interleaved 32x32 tiles with the same per-pixel work;
-  --scaling strong the frame stays `size` x `size` for every N -- BASELINE.json configs[3] is
-                   `--workload dragon --size 2048 --spp 4096 --scaling strong --gpus 8`.
+  --scaling strong (default) the frame stays `size` x `size` for every N: the default is the metric's frame (1024 x 1024, 1024 spp), and
+                   BASELINE.json configs[3] is `--workload dragon --size 2048 --spp 4096 --gpus 8`.  The samples of a pixel are a serial chain
+                   (one engine, one estimator: reference src/worker.cpp:149-326), so a share of 1/N of the pixels is NOT 1/N of the time:
+                   tools/share_rehearsal.py measures every rank's share on one GPU (profiles/r03_share_rehearsal.txt);
+  --scaling weak   the same view at sqrt(N) times the resolution per side (1448, 2048, 2896 pixels for 2, 4, 8 GPUs):
+                   every GPU renders `size`^2 pixels of interleaved 32x32 tiles with the same per-pixel work.
 Inputs are synthetic (procedural mesh), resident in HBM before the timed region; scene build/upload is reported separately.
 
 Prints ONE JSON line on rank 0.
@@ -105,30 +108,14 @@ def ref_formula_bytes_per_sample(R, A, T, V):
     return R * (A * 32.0 + T * 36.0 + 96.0) + V * 100.0 + 16.0
 
 
-def measured_traffic(workload_key):
-    """HBM bytes per SAMPLE from the newest profiles/r*_traffic.json (written by tools/measure_traffic.py from separate rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE passes over the same workload, with the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE
-    counts 64 B per 128-B request, calibrated on tools/gather_bench.hip).  None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    for path in reversed(files):
-        try:
-            entry = json.load(open(path)).get(workload_key)
-        except (OSError, ValueError):
-            continue
-        if entry and entry.get("bytes_per_sample"):
-            return entry["bytes_per_sample"], os.path.relpath(path, ROOT)
-    return None, None
-
-
 def cpu_baseline(sc, cam, opt, seconds_target):
     """The reference itself (oracle/_ref, kind "reference") or, if that was not built, the C restatement (kind "port"),
     timed on this host's cores on a bounded random subset of the SAME frame's pixels (same scene, same spp)."""
     import oracle
-    # the reference's default worker count is hardware_concurrency() - 1 (src/worker.cpp:366); a GPU box grants this job
-    # a 16-core share of the host, so the count is taken from that share, not from the machine's 256 logical CPUs
-    share = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2), int(os.environ.get("PT_CPU_SHARE", "16")))
-    threads = max(share - 1, 1)
+    # the reference's default worker count is hardware_concurrency() - 1 (src/worker.cpp:366), taken here from the CPUs this job may
+    # really use (host_cpus: affinity mask, cgroup quota), not from the machine's logical CPU count
+    host = host_cpus()
+    threads = max(host["usable"] - 1, 1)
     try:
         chk, kind = oracle.Checker("ref", ndebug=True), "reference"
     except (FileNotFoundError, OSError):
@@ -157,7 +144,42 @@ def cpu_baseline(sc, cam, opt, seconds_target):
         t_run = run(n1)
     h.close()
     return {"value": n1 * spp / t_run / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
-            "sample": "%d random pixels of the same %dx%d frame at %d spp (%.1f s); scene build %.1f s" % (n1, w, hgt, spp, t_run, build_s)}
+            "sample": "%d random pixels of the same %dx%d frame at %d spp (%.1f s); scene build %.1f s" % (n1, w, hgt, spp, t_run, build_s),
+            "host": host}
+
+
+def host_cpus():
+    """What this process may use of the host: logical CPUs of the machine, size of the affinity mask, cgroup CPU quota (v2 cpu.max or v1
+    cfs quota), and the count the baseline goes by = the smallest of them (PT_CPU_SHARE overrides, and says so).  BASELINE.md asks for
+    nproc, the core count used and the CPU model next to the number."""
+    nproc = os.cpu_count() or 1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    usable = min(affinity, int(quota + 0.5) if quota else affinity)
+    source = "affinity mask" if usable == affinity else "cgroup quota"
+    if os.environ.get("PT_CPU_SHARE"):
+        usable, source = max(int(os.environ["PT_CPU_SHARE"]), 1), "PT_CPU_SHARE"
+    return {"nproc": nproc, "affinity": affinity, "cgroup_quota": quota, "usable": max(usable, 1), "usable_from": source, "cpu_model": model}
 
 
 def parse_args(argv=None):
@@ -166,7 +188,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dragon")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
+    ap.add_argument("--no-weak-extra", action="store_true", help="N > 1, strong: skip the extra step of the weak-scaling frame")
     ap.add_argument("--size", type=int, default=1024, help="pixels per side: at one GPU (weak: sqrt(N) times as many at N GPUs) or of the fixed frame (strong)")
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--mesh-n", type=int, default=1900, help="stand-in mesh resolution (nu = nv); 1900 -> 7.2 M triangles")
@@ -286,6 +309,7 @@ def run_rank(args):
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    scaling = args.scaling if world > 1 else "none"  # one GPU: nothing scales
     width, height = frame_for(world, args.size, args.scaling)
     base_seed = args.seed
     scene = None
@@ -316,15 +340,35 @@ def run_rank(args):
 
     # A step is one launch of the path kernel per rank.  Asking for statistics does not change the launch: the kernel always counts its
     # work in per-wave registers; the library then reads two HIP events recorded around the launch and the counters (128 KB) back.
-    for _ in range(args.warmup):
-        job.render()
-    sync()
-    t0 = time.perf_counter()
-    stats = None
-    for _ in range(args.steps):
-        stats = job.render(want_stats=not standin)
-    sync()
-    elapsed = time.perf_counter() - t0
+    def timed(the_job, warmup, steps):
+        for _ in range(warmup):
+            the_job.render()
+        sync()
+        t_begin = time.perf_counter()
+        st = None
+        for _ in range(steps):
+            st = the_job.render(want_stats=not standin)
+        sync()
+        return time.perf_counter() - t_begin, st
+
+    elapsed, stats = timed(job, args.warmup, args.steps)
+    # N > 1 on the metric's fixed frame: one more step on the weak-scaling frame (the same view at sqrt(N) times the resolution per side,
+    # the same pixels per GPU as the one-GPU run), reported under "weak" -- never as `value`
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak_extra:
+        w2, h2 = frame_for(world, args.size, "weak")
+        from cpupathtrace_amd import scenes as _scenes
+        opt2 = _scenes.options(w2, h2, args.spp, args.spp)
+        if standin:
+            job2 = sharding.ShardedJob(None, None, opt2, rank, world, device, base_seed=base_seed, render_fn=standin_render_fn(w2, base_seed))
+        else:
+            job2 = sharding.ShardedJob(scene, cam, opt2, rank, world, device, base_seed=base_seed, staged_gather=(backend == "gloo"))
+        t2, _ = timed(job2, 1, 1)
+        times = [None] * world
+        dist.all_gather_object(times, t2)
+        weak = {"frame": "%dx%d" % (w2, h2), "ms_per_step": max(times) * 1e3, "value": float(w2) * h2 * args.spp / max(times) / 1e6, "unit": "Msamples/s",
+                "steps": 1, "warmup": 1, "note": "same view at sqrt(N) times the resolution per side: %d pixels per GPU, as in the one-GPU run" % (w2 * h2 // world)}
+        del job2
     my_pixels = int(sum(int(t["w"]) * int(t["h"]) for t in job.mine))
     mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "tiles": int(job.n_local_tiles), "pixels": my_pixels, "elapsed_s": elapsed,
             "device_name": torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu",
@@ -345,16 +389,20 @@ def run_rank(args):
         value = total_samples / elapsed / 1e6
         out = {
             "metric": "Msamples/s (all bounces)" if not standin else "INVALID (stand-in renderer, test only)", "value": value, "unit": "Msamples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not standin else "stand-in renderer (test only)",
             "config": {"workload": "%s, %dx%d, %d spp (min = max), per-pixel engines seeded from base seed %d" % (label, width, height, args.spp, args.seed),
                        "objects": int(len(sc["obj_kind"])), "bvh_depth": int(info["depth"]), "tiles_per_gpu": int(job.n_local_tiles),
                        "tiles_total": int(len(job.tiles)),
-                       "parallelism": "tiles interleaved over %d GPU(s), scene replicated, %s gather to rank 0" % (world, "RCCL" if backend == "nccl" else backend),
+                       "parallelism": ("one GPU: one persistent launch per frame, no gather" if world == 1 else
+                                       "tiles dealt round-robin to %d GPUs (diagonals of the tile grid), scene replicated, one %s gather of the finished tiles to rank 0 per frame"
+                                       % (world, "RCCL" if backend == "nccl" else backend)),
                        "scene_build_s": create_s, "scene_generate_s": gen_s},
             "distributed": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else "none"),
                             "gather_bytes_per_step": int(job.gather_bytes), "ranks": per_rank},
         }
+        if weak is not None:
+            out["weak"] = weak
         if stats is not None:
             out["roofline"] = roofline(stats, args, value, world)
         if world == 1 and args.cpu_seconds > 0 and not standin:
@@ -369,13 +417,48 @@ def run_rank(args):
     return 0
 
 
+def profile_entry(pattern, keys):
+    """The newest profiles/<pattern> JSON that has one of `keys`: (entry, file) or (None, None)."""
+    import glob
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))):
+        try:
+            data = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for k in keys:
+            if data.get(k):
+                return data[k], os.path.relpath(path, ROOT)
+    return None, None
+
+
+L1_LOOKUP_LIMIT = 1.5   # lane look-ups per clock per CU from L1 for scattered 64-byte records (tools/ta_probe.hip, profiles/r02_ta_probe.txt)
+CLOCK_HZ = 2.4e9        # MI355X peak shader clock; the chip runs at or below it, so per-clock figures computed with it are lower bounds
+
+
+def bound_from_counters(d, hbm_frac):
+    """What bounds the kernel, from its PMC figures (tools/pmc_summary.py): the most utilised resource if one is at 75 % or more, otherwise
+    latency -- the waves spend their cycles waiting (s_waitcnt) while no unit is near its limit."""
+    use = {"hbm": hbm_frac or 0.0, "valu": d["valu_busy"], "l1_lookups": d["l1_accesses_per_clk_cu"] / L1_LOOKUP_LIMIT}
+    top = max(use, key=use.get)
+    if use[top] >= 0.75:
+        return top, use
+    return ("latency" if d["waves_waiting"] >= 0.4 else "issue"), use
+
+
 def roofline(s, args, msamples_per_s, world):
-    """Dominant kernel = pt_path_kernel, ONE launch per step.  `achieved` / `frac` are SURVEY.md 8(d)'s figure: ALGORITHMIC bytes per launch
-    (the formula, with the kernel's own work counters of that launch) divided by the launch's duration (HIP events on the library's
-    stream around the launch, last timed step), against the HBM peak -- a work rate, NOT a bandwidth utilisation.  What the memory
-    system actually moves is reported next to it: `traffic` (PMC bytes per launch, from profiles/), `hbm_frac` (PMC bytes per second /
-    8 TB/s) and `l2_frac` (algorithmic bytes per second / the L2's 34.5 TB/s: every node record that is not an L1 hit comes from
-    there).  `bound` says what the counters say (profiles/): dependent record fetches in SIMT lockstep, not bandwidth."""
+    """Dominant kernel = pt_path_kernel, ONE launch per step.
+
+    `achieved` / `frac` are SURVEY.md 8(d)'s figure and nothing else: ALGORITHMIC bytes per launch (the formula, with the kernel's own work
+    counters of that launch -- checked against the oracle's counters in tests/test_gpu_parity.py) divided by the launch's duration (HIP
+    events on the library's stream around the launch, last timed step), against the HBM peak.  The formula bills every node visit as a
+    fetch from HBM, so this is a WORK RATE in bandwidth units: caches make it exceed what HBM moves, and it is not bounded by 1.
+    `algorithmic_gbs` repeats it under an honest name.  The figures that ARE bounded by 1 sit in `ceiling`:
+      hbm         measured HBM bytes per second (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/) / 8 TB/s
+      l1_lookups  16-byte lane look-ups of record fetches per clock per CU (4 per node or leaf visit, counted by the kernel) / the 1.5 the
+                  texture addresser delivers for scattered records (tools/ta_probe.hip); computed with the 2.4 GHz peak clock: a lower bound
+      replay      ray rate / the rate of the traversal ALONE on the same frame's rays (pt_replay_kernel, tools/replay_probe.py, profiles/):
+                  what a tracer that pays nothing for shading, queues and slot state would deliver
+    `bound` is derived from the kernel's PMC figures of the same workload (profiles/r*_pmc_derived.json), not written by hand."""
     samples = max(s["samples"], 1)
     R = s["rays_traced"] / samples
     A = (2.0 * s["node_visits"] + s["rays_traced"]) / max(s["rays_traced"], 1)  # two slab tests per inner node + the root test
@@ -385,14 +468,34 @@ def roofline(s, args, msamples_per_s, world):
     launches = max(s["launches"], 1)
     kernel_s = max(s["kernel_ms"], 1e-6) / 1e3
     achieved = bytes_per_sample * samples / kernel_s / 1e9
-    per_sample, source = measured_traffic("%s-%d" % (args.workload, args.mesh_n if args.workload.startswith("dragon") else 0))
-    return {"bound": "latency", "bound_note": "dependent record fetches in SIMT lockstep at 4 waves per SIMD; HBM and L2 bandwidth are far from saturated (hbm_frac, l2_frac)",
+    mesh = args.mesh_n if args.workload.startswith("dragon") else 0
+    keys = ["%s-%d-%d" % (args.workload, mesh, args.size), "%s-%d" % (args.workload, mesh)] if args.size == 1024 else ["%s-%d-%d" % (args.workload, mesh, args.size)]
+    traffic, traffic_file = profile_entry("r*_traffic.json", keys)
+    per_sample = traffic["bytes_per_sample"] if traffic else None
+    hbm_frac = (per_sample * samples / kernel_s / 1e9 / HBM_PEAK_GBS) if per_sample else None
+    pmc, pmc_file = profile_entry("r*_pmc_derived.json", keys)
+    replay, replay_file = profile_entry("r*_replay.json", keys)
+    rays_per_s = s["rays_traced"] / kernel_s
+    lookups = 4.0 * (s["node_visits"] + s["leaf_tests"]) / kernel_s / CLOCK_HZ / 256.0
+    ceiling = {"hbm": {"frac": hbm_frac, "achieved_gbs": (per_sample * samples / kernel_s / 1e9) if per_sample else None, "peak_gbs": HBM_PEAK_GBS, "source": traffic_file},
+               "l1_lookups": {"frac": lookups / L1_LOOKUP_LIMIT, "per_clk_per_cu": lookups, "limit": L1_LOOKUP_LIMIT, "clock_hz_assumed": CLOCK_HZ},
+               "replay": {"frac": (rays_per_s / replay["rays_per_s"]) if replay else None, "rays_per_s": rays_per_s,
+                          "traversal_alone_rays_per_s": replay["rays_per_s"] if replay else None, "source": replay_file}}
+    if pmc:
+        bound, use = bound_from_counters(pmc, hbm_frac)
+        note = ("from %s: waves waiting %.0f %% of their cycles, vector ALUs %.0f %% busy, L1 %.2f look-ups per clock per CU (limit %.1f), L1 hit rate %.1f %%, L2 hit rate %.0f %%, "
+                "HBM %.0f %% of peak" % (pmc_file, 100 * pmc["waves_waiting"], 100 * pmc["valu_busy"], pmc["l1_accesses_per_clk_cu"], L1_LOOKUP_LIMIT, 100 * pmc["l1_hit"],
+                                         100 * pmc["l2_hit"], 100 * (hbm_frac or 0.0)))
+    else:
+        bound, use, note = None, None, "no PMC profile of this workload under profiles/: not derived"
+    return {"bound": bound, "bound_note": note, "utilisation": use,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": per_sample * samples / launches if per_sample else None, "traffic_source": source,
+            "frac_is": "SURVEY 8(d) work rate (algorithmic bytes / time / HBM peak): not bounded by 1; the bounded figures are in `ceiling`",
+            "algorithmic_gbs": achieved,
+            "traffic": per_sample * samples / launches if per_sample else None, "traffic_source": traffic_file,
             "kernel": "pt_path_kernel", "launches_per_step": launches, "avg_launch_ms": s["kernel_ms"] / launches,
             "algorithmic_bytes_per_launch": bytes_per_sample * samples / launches, "algorithmic_bytes_per_sample": bytes_per_sample,
-            "hbm_frac": (per_sample * samples / kernel_s / 1e9 / HBM_PEAK_GBS) if per_sample else None,
-            "l2_frac": achieved / L2_PEAK_GBS,
+            "hbm_frac": hbm_frac, "l2_frac": achieved / L2_PEAK_GBS, "ceiling": ceiling,
             "per_sample": {"rays": R, "aabb_tests_per_ray": A, "leaf_tests_per_ray": T, "vertices": V},
             "wavefronts": s["wavefronts"], "slot_rows": s["slot_rows"], "wave_steps": s["wave_steps"], "shading_passes": s["shading_passes"],
             "walks_per_wave_step": (s["node_visits"] + s["leaf_tests"]) / max(s["wave_steps"], 1)}

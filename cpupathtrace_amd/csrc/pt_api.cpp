@@ -182,10 +182,15 @@ struct pt_scene {
     PtPathArgs host_path_args{};   // ... and the host copy they are uploaded from
     DevBuf<unsigned long long> path_wave_counters;
     uint32_t *host_tiles_done = nullptr; // pinned: tiles finished so far, written by the kernel (progress callback)
+    unsigned long long *host_streams_done = nullptr; // pinned: the launch's count of finished streams, copied behind every launch
+    uint64_t streams_expected = 0;                   // ... and what it must read once the stream has drained (finish_path)
 
     ~pt_scene() {
         if(host_tiles_done != nullptr) {
             (void)hipHostFree(host_tiles_done);
+        }
+        if(host_streams_done != nullptr) {
+            (void)hipHostFree(host_streams_done);
         }
         if(stream != nullptr) {
             (void)hipStreamDestroy(stream);
@@ -295,6 +300,7 @@ int setup_path(pt_scene *s) {
     cfg.spill_depth = s->depth > static_cast<uint32_t>(cfg.stack_lds) ? s->depth - static_cast<uint32_t>(cfg.stack_lds) : 1U;
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 12), 1), 64);
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
+    cfg.ready_shift = std::min(std::max(env_int("PT_READY_SHIFT", 1), 0), 31);
     cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 12), 1), 64);
     cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", cfg.in_lds ? 8 : 4), 1), 64); // measured: 4 for trees in HBM, 8 for scenes in LDS
     if(env_int("PT_DEBUG", 0) != 0) {
@@ -325,9 +331,15 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     uint32_t slots_per_wave = std::min<uint32_t>(static_cast<uint32_t>(cfg.rows) * 64U, std::max<uint32_t>(1U, (n + waves - 1U) / waves));
     // The first round of streams goes to the slots in pieces of `first_lanes` neighbouring slots (pt_path.hip, stream hand-out): a
     // wavefront's slots are a whole number of pieces (a large job gets up to 7 more slots per wavefront, a small one pieces of 1).
-    uint32_t first_lanes = static_cast<uint32_t>(env_int("PT_FIRST_LANES", 8)); // measured: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440, 4 -> 431 Msamples/s
+    // A job that fits the slots in ONE round (nothing left to pull: every strong-scaling share of a frame, every small frame) has no
+    // dynamic balance at all, and its duration is that of the wavefront with the most expensive streams -- whose samples are sequential, so
+    // the streams that happen to share a wavefront with them wait for the same passes.  Such a job is dealt stream by stream (pieces of 1:
+    // slot q of wavefront w renders stream q * waves + w), which gives every wavefront a sample of the whole job: the 1/8 share of the
+    // benchmark frame 273 -> 221 ms at 256 spp, the 1/4 share 317 -> 259 (profiles/r03_share_rehearsal.txt).
+    const bool single_round = static_cast<uint64_t>(waves) * slots_per_wave >= n;
+    uint32_t first_lanes = static_cast<uint32_t>(env_int("PT_FIRST_LANES", single_round ? 1 : 8)); // full frame: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440, 4 -> 431 Msamples/s
     if(first_lanes == 0 || first_lanes > 64 || (first_lanes & (first_lanes - 1U)) != 0) {
-        first_lanes = 8;
+        first_lanes = single_round ? 1 : 8;
     }
     if(slots_per_wave % first_lanes != 0) {
         if(slots_per_wave >= 64U) {
@@ -380,6 +392,21 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     s->path_waves = waves;
     s->path_cap = cap;
     *out_cfg = cfg;
+    return PT_OK;
+}
+
+// Wait for the scene's stream and make sure the last launch rendered every stream it was given: a wavefront that left early or a stream
+// lost in the hand-out would otherwise return stale pixels with PT_OK.  Every entry point that synchronises anyway ends with this.
+int finish_path(pt_scene *s) {
+    PT_HIP(hipStreamSynchronize(s->stream));
+    if(s->host_streams_done != nullptr && s->streams_expected != 0) {
+        const unsigned long long done = *static_cast<volatile unsigned long long *>(s->host_streams_done);
+        const uint64_t expected = s->streams_expected;
+        s->streams_expected = 0;
+        if(done != expected) {
+            return fail(PT_ERR_HIP, "path kernel ended with " + std::to_string(done) + " of " + std::to_string(expected) + " streams finished");
+        }
+    }
     return PT_OK;
 }
 
@@ -450,6 +477,13 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     pt_launch_path(st, s->dev, cam, opt, S, T, Q, cfg, d_image, s->counters.ptr, &s->host_path_args, s->path_args.ptr);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(ev_end.e, st));
+    // every launch leaves its count of finished streams in pinned memory; whoever waits for the stream next compares it (finish_path)
+    if(s->host_streams_done == nullptr) {
+        PT_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->host_streams_done), 64, hipHostMallocDefault));
+    }
+    *s->host_streams_done = ~0ULL;
+    s->streams_expected = T.n;
+    PT_HIP(hipMemcpyAsync(s->host_streams_done, &s->counters.ptr->streams_done, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if(T.tiles_done != nullptr) {
         const int total = static_cast<int>(T.n_tiles);
         int reported = 0;
@@ -1282,8 +1316,7 @@ int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_opti
         if(out_states != nullptr) {
             PT_HIP(hipMemcpyAsync(out_states, s->st_rng.ptr, n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         }
-        PT_HIP(hipStreamSynchronize(st));
-        return PT_OK;
+        return finish_path(s);
     }
 }
 
@@ -1393,8 +1426,7 @@ int pt_render_tiles_progress(pt_scene *s, const pt_camera_params *camera, const 
         return rc;
     }
     PT_HIP(hipMemcpyAsync(out_image, s->image.ptr, pixels * sizeof(F4), hipMemcpyDeviceToHost, s->stream));
-    PT_HIP(hipStreamSynchronize(s->stream));
-    return PT_OK;
+    return finish_path(s);
 }
 
 int pt_render_item(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_stream *item, float *out_tile, uint64_t *out_state,
@@ -1453,8 +1485,7 @@ int pt_render_item(pt_scene *s, const pt_camera_params *camera, const pt_options
     if(out_state != nullptr) {
         PT_HIP(hipMemcpyAsync(out_state, s->st_rng.ptr, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     }
-    PT_HIP(hipStreamSynchronize(st));
-    return PT_OK;
+    return finish_path(s);
 }
 
 int pt_render_tiles_multi(pt_scene *const *scenes, int n_scenes, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles,
@@ -1480,10 +1511,19 @@ int pt_render_tiles_multi(pt_scene *const *scenes, int n_scenes, const pt_camera
             return fail(PT_ERR_INVALID, "tile outside the image or empty");
         }
     }
-    // The multi-device form of doWorkParallel (src/worker.cpp:364-387): tile k goes to scene k % n_scenes (each scene a replica on its
-    // own device), one host thread per scene drives its device, every device renders into its own frame in HBM, and the frames meet in the
-    // caller's image (one device-to-host copy per device, then the rows of that device's tiles).  Engines are per pixel, so the image
-    // does not depend on n_scenes.  progress calls are serialised and counted over all devices.
+    // The multi-device form of doWorkParallel (src/worker.cpp:364-387): the tiles are dealt round-robin to the scenes (each a replica on its
+    // own device; along the diagonals of a grid whose rows hold a multiple of n_scenes tiles, so that no device gets whole columns of the
+    // frame -- cpupathtrace_amd/sharding.py uses the same rule), one host thread per scene drives its device, every device renders into its
+    // own frame in HBM and only the rectangles of ITS tiles travel to the caller's image.  Engines are per pixel, so the image does not
+    // depend on n_scenes.  progress calls are serialised and counted over all devices.
+    size_t per_row = 0;
+    while(per_row < n_tiles && tiles[per_row].y == tiles[0].y) {
+        per_row++;
+    }
+    const bool diagonal = n_scenes > 1 && per_row > 0 && n_tiles % per_row == 0 && per_row % static_cast<size_t>(n_scenes) == 0;
+    auto owner = [&](size_t k) -> int {
+        return static_cast<int>((diagonal ? k % per_row + k / per_row : k) % static_cast<size_t>(n_scenes));
+    };
     struct Shared {
         std::mutex progress_mutex;
         int completed = 0, total = 0;
@@ -1504,14 +1544,15 @@ int pt_render_tiles_multi(pt_scene *const *scenes, int n_scenes, const pt_camera
     const size_t width = static_cast<size_t>(options->image_width), pixels = width * static_cast<size_t>(options->image_height);
     auto work = [&](int i) {
         std::vector<pt_tile> mine;
-        for(size_t k = static_cast<size_t>(i); k < n_tiles; k += static_cast<size_t>(n_scenes)) {
-            mine.push_back(tiles[k]);
+        for(size_t k = 0; k < n_tiles; k++) {
+            if(owner(k) == i) {
+                mine.push_back(tiles[k]);
+            }
         }
         if(mine.empty()) {
             return;
         }
         pt_scene *s = scenes[i];
-        std::vector<float> frame(pixels * 4);
         auto run = [&]() -> int {
             std::lock_guard<std::mutex> lock(s->render_mutex);
             PT_HIP(hipSetDevice(s->device));
@@ -1521,20 +1562,16 @@ int pt_render_tiles_multi(pt_scene *const *scenes, int n_scenes, const pt_camera
             if(rc != PT_OK) {
                 return rc;
             }
-            PT_HIP(hipMemcpyAsync(frame.data(), s->image.ptr, pixels * sizeof(F4), hipMemcpyDeviceToHost, s->stream));
-            PT_HIP(hipStreamSynchronize(s->stream));
-            return PT_OK;
+            for(const pt_tile &t : mine) {
+                const size_t at = static_cast<size_t>(t.y) * width + static_cast<size_t>(t.x);
+                PT_HIP(hipMemcpy2DAsync(out_image + at * 4, width * sizeof(F4), s->image.ptr + at, width * sizeof(F4), static_cast<size_t>(t.w) * sizeof(F4),
+                                        static_cast<size_t>(t.h), hipMemcpyDeviceToHost, s->stream));
+            }
+            return finish_path(s);
         };
         rcs[static_cast<size_t>(i)] = run();
         if(rcs[static_cast<size_t>(i)] != PT_OK) {
             errors[static_cast<size_t>(i)] = g_last_error; // this thread's message
-            return;
-        }
-        for(const pt_tile &t : mine) {
-            for(int y = t.y; y < t.y + t.h; y++) {
-                const size_t at = (static_cast<size_t>(y) * width + static_cast<size_t>(t.x)) * 4;
-                std::memcpy(out_image + at, frame.data() + at, static_cast<size_t>(t.w) * 4 * sizeof(float));
-            }
         }
     };
     if(stats != nullptr) {
@@ -1583,6 +1620,11 @@ int pt_render_tiles_device(pt_scene *s, const pt_camera_params *camera, const pt
     if(rc == PT_OK) {
         PT_HIP(hipEventRecord(ev.e, s->stream));
         PT_HIP(hipStreamWaitEvent(caller, ev.e, 0));
+        // This entry point does not wait for the device (the frame stays in HBM for the caller's stream).  With statistics it has waited
+        // and checked already (run_path); PT_VERIFY=1 makes every call wait and check.
+        if(stats == nullptr && env_int("PT_VERIFY", 0) != 0) {
+            rc = finish_path(s);
+        }
     }
     return rc;
 }

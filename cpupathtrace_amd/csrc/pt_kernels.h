@@ -91,7 +91,8 @@ struct PtPathConfig {
     size_t lds_bytes;
     int in_lds;           // whole tree + triangle records staged in LDS (small scenes)
     int refill_idle;      // idle lanes that make a wavefront refill from its queue (or shade when the queue is empty)
-    int min_ready;        // slots that must be ready before a wavefront with walks in progress stops tracing to shade
+    int min_ready;        // slots that must be ready before a wavefront with walks in progress stops tracing to shade ...
+    int ready_shift;      // ... or (slots that still hold or may get a stream) >> ready_shift, if that is less: a wavefront whose last streams are running shades them as they come
     int burst_steps;      // traversal steps between two looks at the queue
     int first_lanes;      // slots per piece of the first round of streams (slots_per_wave is a multiple of it)
     int leaf_min;         // lanes that must stand on a leaf before the leaf code runs (while other lanes still have nodes to visit)
@@ -108,7 +109,7 @@ struct PtPathArgs {
     PtSlots S;
     PtStreams T;
     PtLocalQueue Q;
-    int rows, slots_per_wave, refill_idle, min_ready, burst_steps, leaf_min;
+    int rows, slots_per_wave, refill_idle, min_ready, burst_steps, leaf_min, ready_shift;
     uint2 *spill;
     uint32_t spill_depth;
     uint32_t save_stride;

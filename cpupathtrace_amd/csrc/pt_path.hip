@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     const PtPathArgs *A = (const PtPathArgs *)A4;
     // what the traversal loop needs, read once
     const int rows = A->rows, slots_per_wave = A->slots_per_wave, refill_idle = A->refill_idle, min_ready = A->min_ready, burst_steps = A->burst_steps,
-              leaf_min = A->leaf_min;
+              leaf_min = A->leaf_min, ready_shift = A->ready_shift;
     PtLocalQueue Q = A->Q;
     RootBox root;
     root.ref = A->sc.root_ref;
@@ -1073,7 +1073,12 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                         const uint32_t word = word_l[r * 64 + lane];
                         n_ready += (uint32_t)__popcll(__ballot(!(PT_W_FLAGS(word) & PT_F_DONE) && PT_W_PENDING(word) == 0));
                     }
-                    if(n_ready >= (uint32_t)min_ready || n_idle == 64u) {
+                    // enough of them for a pass: `min_ready`, or a share of the slots that are still alive -- a wavefront that is down to its
+                    // last few streams must not make each of them wait for all the others (their samples are sequential: the launch lasts as
+                    // long as its slowest stream)
+                    const uint32_t live_share = (n_slots - ctx.n_dead) >> ready_shift;
+                    const uint32_t need = live_share < (uint32_t)min_ready ? (live_share > 1u ? live_share : 1u) : (uint32_t)min_ready;
+                    if(n_ready >= need || n_idle == 64u) {
                         want_pass = true;
                         break;
                     }
@@ -1411,6 +1416,7 @@ void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCame
     a.min_ready = cfg.min_ready;
     a.burst_steps = cfg.burst_steps;
     a.leaf_min = cfg.leaf_min;
+    a.ready_shift = cfg.ready_shift;
     a.spill = cfg.spill;
     a.spill_depth = cfg.spill_depth;
     a.save_stride = (uint32_t)cfg.grid * 256u;

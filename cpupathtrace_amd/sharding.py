@@ -1,9 +1,10 @@
 """Tile sharding of one frame over the GPUs of a node: the multi-GPU form of the reference's tile queue.
 
 The reference cuts a frame into <= 32x32 tiles and lets its worker threads pull them from one queue; tiles never talk to
-each other (src/worker.cpp:328-424).  Here every rank (one process per GPU, torch.distributed over RCCL) owns the tiles
-`tile_index % world == rank` of the same list, renders them with the replicated scene, and the only exchange is the
-gather of finished tiles to rank 0 at the end of a frame.  Because every pixel has its own engine seeded from
+each other (src/worker.cpp:328-424).  Here every rank (one process per GPU, torch.distributed over RCCL) owns every world-th
+tile of the same list (`tile_owner`: dealt round-robin along the rows of the tile grid, and along its diagonals when the rows
+are a multiple of the world size, so that a rank never ends up with whole columns of the frame), renders them with the
+replicated scene, and the only exchange is the gather of finished tiles to rank 0 at the end of a frame.  Because every pixel has its own engine seeded from
 (base_seed, x, y), the assembled frame is bit-identical for any number of ranks.
 """
 import numpy as np
@@ -13,8 +14,23 @@ import torch.distributed as dist
 from . import binding
 
 
+def tile_owner(tiles, world):
+    """Rank of every tile.  Tile k of processJob's row-major list goes to rank k % world; when the grid's rows hold a multiple of
+    `world` tiles that would give every rank whole COLUMNS of the frame (with 32 tiles per row and 8 ranks: columns r, r + 8, ...,
+    and the ranks' loads differ by what their columns show), so every grid row is then shifted by one more rank: (column + row) % world.
+    Same rule in pt_render_tiles_multi (cpupathtrace_amd/csrc/pt_api.cpp)."""
+    k = np.arange(len(tiles), dtype=np.int64)
+    if world <= 1 or len(tiles) == 0:
+        return np.zeros(len(tiles), np.int64)
+    per_row = int((tiles["y"] == tiles["y"][0]).sum())
+    regular = per_row > 0 and len(tiles) % per_row == 0 and bool((tiles["y"][:per_row] == tiles["y"][0]).all())
+    if regular and per_row % world == 0:
+        return (k % per_row + k // per_row) % world
+    return k % world
+
+
 def local_tiles(tiles, rank, world):
-    return tiles[rank::world]
+    return tiles[tile_owner(tiles, world) == rank]
 
 
 def pixel_indices(tiles, width):

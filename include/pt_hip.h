@@ -124,8 +124,10 @@ int pt_device_count(void);
 
 const char *pt_last_error(void);
 
-/* Scene::Scene (src/scene/scene.cpp:153-181): builds the reference's BVH topology (impl::constructBVH, scene.cpp:12-102) on
- * the host, registers emissive objects (scene.cpp:183-208), flattens everything into device arrays on `device`.
+/* Scene::Scene (src/scene/scene.cpp:153-181): builds the reference's BVH topology (impl::constructBVH, scene.cpp:12-102) -- on
+ * the device, level by level (pt_build.hip), for scenes of PT_BUILD_DEVICE_MIN (1024) objects and more, by the same recursion on the host
+ * for smaller ones; the two produce the same tree bit for bit -- registers emissive objects (scene.cpp:183-208) and lays everything out
+ * in device arrays on `device`.
  * PT_ERR_UNSUPPORTED: more than 8 light samples per path vertex (point lights + min(2 + log10(E + 1), E) object samples),
  * or a BVH deeper than 128 levels.
  * Thread safety: calls on DIFFERENT scenes may run concurrently; render and intersection calls on the SAME scene are serialised inside
@@ -166,21 +168,28 @@ int pt_render_tiles(pt_scene *scene, const pt_camera_params *camera, const pt_op
 
 /* Same, reporting progress the way processJob's progress_callback does (worker.h:75-84, src/worker.cpp:354-360): `progress(completed,
  * total, user)` is called from the CALLING thread, never concurrently, with completed = 1 .. n_tiles in increasing order, while the
- * device is still rendering (the kernel counts finished tiles in host-visible memory; the host polls).  NULL = no reporting. */
+ * device is still rendering (the kernel counts finished tiles in host-visible memory; the host polls).  NULL = no reporting.
+ * The callback runs while the library holds the scene's render lock: it must not call back into the library with the same scene (a
+ * preview through processItem would wait for itself), and it must not throw through this C interface (src/host/worker.cpp keeps a
+ * C++ callback's exception and throws it again after the call). */
 typedef void (*pt_progress_fn)(int completed, int total, void *user);
 int pt_render_tiles_progress(pt_scene *scene, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles,
                              uint64_t base_seed, float *out_image, pt_stats *stats, pt_progress_fn progress, void *user);
 
 /* processJob on several devices of one node -- the multi-device form of doWorkParallel (src/worker.cpp:364-387).  scenes[i] are replicas of
- * one scene created on different devices (pt_scene_create(device_i, same desc)); tile k is rendered by scenes[k % n_scenes], one host
- * thread per scene, and the finished tiles of every device are copied into out_image.  The image is identical for every n_scenes
- * (per-pixel engines).  stats, if not NULL, is an array of n_scenes entries; progress as in pt_render_tiles_progress, counted over
- * all devices. */
+ * one scene created on different devices (pt_scene_create(device_i, same desc)); the tiles are dealt round-robin to the scenes (tile k to
+ * scenes[k % n_scenes]; along the diagonals of the tile grid when its rows hold a multiple of n_scenes tiles, so that no device renders
+ * whole columns of the frame), one host thread per scene, and only the rectangles of a device's own tiles are copied into out_image.
+ * The image is identical for every n_scenes (per-pixel engines).  stats, if not NULL, is an array of n_scenes entries.  progress as in
+ * pt_render_tiles_progress, counted over all devices and never concurrent -- but with n_scenes > 1 it is called from the library's
+ * worker threads (as the reference calls it from its worker threads, worker.h:75-78), not from the calling thread.
+ * MEASURED ONLY WITH REPLICAS ON ONE DEVICE so far (tests): no multi-GPU node was available to the build. */
 int pt_render_tiles_multi(pt_scene *const *scenes, int n_scenes, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles,
                           size_t n_tiles, uint64_t base_seed, float *out_image, pt_stats *stats, pt_progress_fn progress, void *user);
 
 /* Same, writing into DEVICE memory (e.g. a torch tensor's data_ptr) and ordered on `stream` (a hipStream_t, NULL = the
- * library's own stream followed by a synchronisation).  Used for the multi-GPU gather over RCCL. */
+ * library's own stream followed by a synchronisation).  Used for the multi-GPU gather over RCCL.  Does not wait for the device unless
+ * `stats` is given; every waiting entry point checks that the launch rendered all its streams, this one with stats or PT_VERIFY=1. */
 int pt_render_tiles_device(pt_scene *scene, const pt_camera_params *camera, const pt_options *options, const pt_tile *tiles, size_t n_tiles,
                            uint64_t base_seed, float *d_out_image, void *stream, pt_stats *stats);
 

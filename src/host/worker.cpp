@@ -3,7 +3,9 @@
 
 #include "../../include/pt_hip.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <exception>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -68,7 +70,7 @@ Image<> processItem(const WorkItem &item, RandomEngine &re) {
     return tile;
 }
 
-Image<> processJob(const FrameRenderJob &job, const std::function<void(int, int)> &progress_callback, int /*worker_count*/) {
+Image<> processJob(const FrameRenderJob &job, const std::function<void(int, int)> &progress_callback, int worker_count) {
     const int width = std::max(job.options.image_width, 0);
     const int height = std::max(job.options.image_height, 0);
     Image<> frame(width, height);
@@ -94,14 +96,34 @@ Image<> processJob(const FrameRenderJob &job, const std::function<void(int, int)
     // The tiles are dealt to the scene's device replicas ($PATHTRACE_DEVICES; one by default) and rendered by one persistent launch
     // per device.  progress_callback is called as the reference calls it (worker.h:75-78, src/worker.cpp:354-360): once per finished
     // tile, (completed, total), never concurrently -- while the devices are still rendering.
+    // An exception thrown by the callback must not cross the C ABI (with several devices it would be thrown on a library thread and end
+    // the program): it is kept, the remaining calls are skipped, and it is thrown again here once the devices have finished.
     struct Forward {
         const std::function<void(int, int)> *fn;
-    } forward{&progress_callback};
-    auto trampoline = [](int completed, int total, void *user) { (*static_cast<Forward *>(user)->fn)(completed, total); };
+        std::exception_ptr failure;
+    } forward{&progress_callback, nullptr};
+    auto trampoline = [](int completed, int total, void *user) {
+        Forward *f = static_cast<Forward *>(user);
+        if(f->failure) {
+            return;
+        }
+        try {
+            (*f->fn)(completed, total);
+        }
+        catch(...) {
+            f->failure = std::current_exception();
+        }
+    };
     static_assert(sizeof(Color<float>) == 4 * sizeof(float), "Image<Color<float>> is a packed RGBA float array");
+    // worker_count (worker.h:83-84; threads in the reference, 0 = as many as the machine has): at most that many of the scene's device
+    // replicas take part.  Every device runs one persistent launch, so there is nothing else for the count to choose.
     const std::vector<pt_scene *> &replicas = job.scene.deviceScenes();
-    check(pt_render_tiles_multi(replicas.data(), static_cast<int>(replicas.size()), &camera, &options, tiles.data(), tiles.size(), base_seed,
-                                reinterpret_cast<float *>(frame.data()), nullptr, trampoline, &forward),
-          "processJob");
+    const int n_replicas = worker_count > 0 ? std::min(worker_count, static_cast<int>(replicas.size())) : static_cast<int>(replicas.size());
+    const int status = pt_render_tiles_multi(replicas.data(), n_replicas, &camera, &options, tiles.data(), tiles.size(), base_seed,
+                                             reinterpret_cast<float *>(frame.data()), nullptr, trampoline, &forward);
+    if(forward.failure) {
+        std::rethrow_exception(forward.failure);
+    }
+    check(status, "processJob");
     return frame;
 }

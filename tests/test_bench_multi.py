@@ -43,15 +43,22 @@ def _check(line, frame_path, world, side, scaling):
     assert np.array_equal(np.load(frame_path), _expected(side, side, 1234)), "every pixel reached rank 0"
 
 
-@pytest.mark.parametrize("scaling,side", [("weak", 88), ("strong", 64)])
+@pytest.mark.parametrize("scaling,side", [("weak", 88), ("strong", 64), (None, 64)])
 def test_bench_spawns_its_own_ranks(tmp_path, scaling, side):
+    """Without --scaling an N > 1 run is on the metric's fixed frame (strong) and carries the weak-scaling frame as an extra field."""
     frame = str(tmp_path / "frame.npy")
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--size", "64", "--spp", "1", "--steps", "1", "--warmup", "1", "--scaling", scaling,
-                        "--frame-out", frame], env=_env(), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--size", "64", "--spp", "1", "--steps", "1", "--warmup", "1"] + (["--scaling", scaling] if scaling else []) +
+                       ["--frame-out", frame], env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "exactly one JSON line"
-    _check(lines[0], frame, 2, side, scaling)
+    _check(lines[0], frame, 2, side, scaling or "strong")
+    out = json.loads(lines[0])
+    if scaling == "weak":
+        assert "weak" not in out
+    else:
+        assert out["weak"]["frame"] == "88x88" and out["weak"]["value"] > 0 and out["weak"]["steps"] == 1
+        assert "%dx%d" % (side, side) in out["config"]["workload"], "`value` is on the fixed frame"
 
 
 def test_bench_under_the_launcher(tmp_path):

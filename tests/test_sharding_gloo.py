@@ -34,7 +34,7 @@ def _worker(rank, world, port, width, height, out_path):
     opt = dict(image_width=width, image_height=height, min_sample_count=1, max_sample_count=1, epsilon=1e-3)
     job = sharding.ShardedJob(None, None, opt, rank, world, torch.device("cpu"), render_fn=render_fn)
     all_tiles = sharding._tiles_py(width, height)
-    assert job.n_local_tiles == len(all_tiles[rank::world])
+    assert job.n_local_tiles == len(sharding.local_tiles(all_tiles, rank, world)) == len(all_tiles[rank::world])
     for _ in range(2):  # two frames through the same buffers
         stats = job.render(want_stats=True)
     assert stats["tiles"] == job.n_local_tiles
@@ -53,6 +53,21 @@ def test_two_rank_gather(tmp_path, width, height):
     mp.spawn(_worker, args=(2, port, width, height, out), nprocs=2, join=True)
     got = np.load(out)
     assert np.array_equal(got, _pattern(width, height))
+
+
+def test_tile_owner_spreads_rows_and_columns():
+    t = sharding._tiles_py(1024, 1024)  # 32 x 32 tiles
+    for world in (2, 4, 8):
+        owner = sharding.tile_owner(t, world)
+        assert (np.bincount(owner, minlength=world) == len(t) // world).all()
+        for r in range(world):
+            mine = t[owner == r]
+            assert len(np.unique(mine["x"])) == 32 and len(np.unique(mine["y"])) == 32, "every rank sees every tile column and row"
+        assert len(np.concatenate([sharding.pixel_indices(sharding.local_tiles(t, r, world), 1024) for r in range(world)])) == 1024 * 1024
+    t = sharding._tiles_py(40, 9)  # 20 tiles of 2 x 2 per row, 5 rows: 100 tiles
+    owner = sharding.tile_owner(t, 3)  # rows are no multiple of 3: plain round-robin
+    assert (owner == np.arange(len(t)) % 3).all()
+    assert (sharding.tile_owner(t[:7], 1) == 0).all()
 
 
 def test_tile_list_matches_reference_rule():

@@ -23,5 +23,5 @@ TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TCP_TCC_READ_REQ_sum
 FETCH_SIZE
 WRITE_SIZE
 GROUPS
-python3 tools/pmc_summary.py "$out" ${PMC_SAMPLES:-0} > "$out/summary.txt"
+python3 tools/pmc_summary.py "$out" ${PMC_SAMPLES:-0} ${PMC_DERIVED:-} ${PMC_KEY:-} > "$out/summary.txt"
 cat "$out/summary.txt"

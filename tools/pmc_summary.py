@@ -1,5 +1,10 @@
-"""Summarise rocprofv3 --pmc csv output per kernel: sum of each counter over all dispatches of a kernel, and per dispatch."""
-import csv, glob, sys, collections
+"""Summarise rocprofv3 --pmc csv output per kernel: sum of each counter over all dispatches of a kernel, and per dispatch.
+
+    python tools/pmc_summary.py <dir with passN/ subdirectories> [samples of the profiled frame] [derived.json workload-key]
+
+With the last two arguments the derived figures of pt_path_kernel are also merged into derived.json under the workload key
+(bench.py reads the newest profiles/r*_pmc_derived.json to say what bounds the kernel)."""
+import csv, glob, json, sys, collections
 root = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -34,6 +39,22 @@ for k in agg:
     print("#   L1 (TCP) hit rate          = %.1f %%   L2 (TCC) hit rate = %.1f %%   mean L1-miss latency = %.0f cycles   L1 stalled on pending misses = %.1f %%" % (
         100 * (1 - v["TCP_TCC_READ_REQ_sum"] / v["TCP_TOTAL_CACHE_ACCESSES_sum"]), 100 * v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]),
         v["TCP_TCC_READ_REQ_LATENCY_sum"] / v["TCP_TCC_READ_REQ_sum"], 100 * v["TCP_PENDING_STALL_CYCLES_sum"] / v["TCP_GATE_EN1_sum"]))
+    if k == "pt_path" and len(sys.argv) > 4:
+        hbm_bytes = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        derived = {"cycles": dur, "waves_waiting": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], "instruction_in_flight": v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"],
+                   "issue_stalls": v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"],
+                   # a wave64 vector instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md, wave scheduling)
+                   "valu_busy": v["SQ_INSTS_VALU"] * 2 / 1024 / dur, "ta_busy": v["GRBM_TA_BUSY"] / v["GRBM_GUI_ACTIVE"],
+                   "l1_accesses_per_clk_cu": v["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256 / dur, "l1_hit": 1 - v["TCP_TCC_READ_REQ_sum"] / v["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                   "l2_hit": v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), "l1_miss_latency_cycles": v["TCP_TCC_READ_REQ_LATENCY_sum"] / v["TCP_TCC_READ_REQ_sum"],
+                   "hbm_bytes": hbm_bytes, "hbm_bytes_per_cycle": hbm_bytes / dur, "l2_requests_per_cycle": v.get("TCC_REQ_sum", 0) / dur,
+                   "samples": samples, "valu_per_sample": v["SQ_INSTS_VALU"] / samples if samples else None, "salu_per_sample": v.get("SQ_INSTS_SALU", 0) / samples if samples else None}
+        try:
+            data = json.load(open(sys.argv[3]))
+        except (OSError, ValueError):
+            data = {}
+        data[sys.argv[4]] = derived
+        json.dump(data, open(sys.argv[3], "w"), indent=1)
     hbm = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
     print("#   HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B) = %.3g B%s" % (hbm, (" = %.0f B per sample (%.3g samples)" % (hbm / samples, samples)) if samples else ""))
     if samples:

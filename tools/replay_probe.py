@@ -30,6 +30,7 @@ lib = binding.load()
 fn = lib.pt_debug_replay_rays
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+top = 0.0
 for parts in (2, 4):
     for waves in (4, 5, 6, 7, 8):
         best = None
@@ -43,4 +44,16 @@ for parts in (2, 4):
         ms_v, o, blocks_v = best
         print("replay, %d waves/SIMD asked (%d workgroups per CU resident), rings in %d parts: %.2f ms, %.2f G rays/s, %d rays, %.1f node visits per ray, %.1f walks per wave step, checksum %x" % (
             waves, blocks_v, parts, ms_v, o[0] / ms_v / 1e6, o[0], o[1] / max(o[0], 1), (o[1] + o[2]) / max(o[3], 1), o[4]), flush=True)
+        top = max(top, o[0] / ms_v * 1e3)
 s.close()
+# PT_REPLAY_JSON=<file>: keep the best rate under the workload's key (bench.py's roofline.ceiling.replay reads the newest profiles/r*_replay.json)
+if os.environ.get("PT_REPLAY_JSON"):
+    import json
+    path = os.environ["PT_REPLAY_JSON"]
+    try:
+        data = json.load(open(path))
+    except (OSError, ValueError):
+        data = {}
+    data["dragon-%d-1024" % mesh_n] = {"rays_per_s": top, "path_kernel_rays_per_s": rays / st["kernel_ms"] * 1e3, "spp": spp,
+                                        "note": "best of 4..8 wavefronts per SIMD and rings replayed in 2 or 4 parts (tools/replay_probe.py)"}
+    json.dump(data, open(path, "w"), indent=1)

@@ -293,7 +293,7 @@ int setup_path(pt_scene *s) {
     int stack_lds = env_int("PT_STACK_LDS", 8);
     cfg.stack_lds = stack_lds == 8 ? 8 : 16;
     cfg.rows = std::min(std::max(env_int("PT_ROWS", 4), 1), PT_MAX_ROWS);
-    cfg.lds_bytes = pt_path_lds_bytes(cfg.stack_lds, cfg.rows, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.n_lds_tris : 0U);
+    cfg.lds_bytes = pt_path_lds_bytes(cfg.stack_lds, cfg.rows, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.n_lds_tris + 1U + s->dev.n_spheres : 0U);
     const int per_cu = pt_path_blocks_per_cu(cfg.stack_lds, cfg.in_lds, cfg.lds_bytes);
     const int limit = env_int("PT_BLOCKS_PER_CU", 0);
     s->path_blocks_per_cu = (limit > 0 && limit < per_cu) ? limit : per_cu;
@@ -301,6 +301,7 @@ int setup_path(pt_scene *s) {
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 12), 1), 64);
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
     cfg.ready_shift = std::min(std::max(env_int("PT_READY_SHIFT", 1), 0), 31);
+    cfg.prefetch = env_int("PT_PREFETCH", 0) != 0 ? 1 : 0;
     cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 12), 1), 64);
     cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", cfg.in_lds ? 8 : 4), 1), 64); // measured: 4 for trees in HBM, 8 for scenes in LDS
     if(env_int("PT_DEBUG", 0) != 0) {
@@ -720,7 +721,8 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         PT_HIP(up(raw_sph, d->sph, 4 * static_cast<size_t>(d->n_spheres)));
         PT_HIP(up(raw_sph_mat, d->sph_material, d->n_spheres));
         PT_HIP(up(raw_sph_obj, s->sph_obj.data(), d->n_spheres));
-        PT_HIP(s->tris.ensure(3 * static_cast<size_t>(d->n_triangles) + 1)); // + 1: a traversal step reads 64 bytes of a 48-byte record
+        PT_HIP(s->tris.ensure(PT_TRI_QUADS * (static_cast<size_t>(d->n_triangles) + 1 + d->n_spheres))); // triangles, a spare record, spheres (pt_types.h)
+        PT_HIP(hipMemsetAsync(s->tris.ptr + PT_TRI_QUADS * static_cast<size_t>(d->n_triangles), 0, PT_TRI_QUADS * sizeof(F4), s->stream));
         PT_HIP(s->tri_shade.ensure(8 * static_cast<size_t>(d->n_triangles)));
         PT_HIP(s->spheres.ensure(d->n_spheres));
         PT_HIP(s->sph_meta.ensure(d->n_spheres));
@@ -837,15 +839,15 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         s->build_ms[0] = ms_since(t_begin);
         const auto t_upload = clock::now();
 
-        std::vector<F4> tris(3 * static_cast<size_t>(d->n_triangles) + 1, F4{0.0F, 0.0F, 0.0F, 0.0F}), shade(8 * static_cast<size_t>(d->n_triangles), F4{0.0F, 0.0F, 0.0F, 0.0F});
+        std::vector<F4> tris(PT_TRI_QUADS * (static_cast<size_t>(d->n_triangles) + 1 + d->n_spheres), F4{0.0F, 0.0F, 0.0F, 0.0F}), shade(8 * static_cast<size_t>(d->n_triangles), F4{0.0F, 0.0F, 0.0F, 0.0F});
         for(uint32_t t = 0; t < d->n_triangles; t++) {
             const float *p = d->tri_pos + 9 * static_cast<size_t>(t);
             const Vec3 a = ld(p), b = ld(p + 3), c = ld(p + 6);
             const Vec3 ab = sub(b, a), ac = sub(c, a);
             const uint32_t obj_cull = s->tri_obj[t] | (d->tri_cull[t] != 0 ? 0x80000000U : 0U);
-            tris[3 * static_cast<size_t>(t) + 0] = {a.x, a.y, a.z, ab.x};
-            tris[3 * static_cast<size_t>(t) + 1] = {ab.y, ab.z, ac.x, ac.y};
-            tris[3 * static_cast<size_t>(t) + 2] = {ac.z, from_bits(d->tri_material[t]), from_bits(obj_cull), 0.0F};
+            tris[PT_TRI_QUADS * static_cast<size_t>(t) + 0] = {a.x, a.y, a.z, ab.x};
+            tris[PT_TRI_QUADS * static_cast<size_t>(t) + 1] = {ab.y, ab.z, ac.x, ac.y};
+            tris[PT_TRI_QUADS * static_cast<size_t>(t) + 2] = {ac.z, from_bits(d->tri_material[t]), from_bits(obj_cull), 0.0F};
             Vec3 na, nb, nc;
             if(d->tri_nrm != nullptr) {
                 const float *q = d->tri_nrm + 9 * static_cast<size_t>(t);
@@ -857,7 +859,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
                 na = nb = nc = normalize(cross(ab, ac)); // Triangle::Triangle, object.cpp:118-124
             }
             for(int k = 0; k < 3; k++) {
-                shade[8 * static_cast<size_t>(t) + k] = tris[3 * static_cast<size_t>(t) + k];
+                shade[8 * static_cast<size_t>(t) + k] = tris[PT_TRI_QUADS * static_cast<size_t>(t) + k];
             }
             shade[8 * static_cast<size_t>(t) + 3] = {na.x, na.y, na.z, nb.x};
             shade[8 * static_cast<size_t>(t) + 4] = {nb.y, nb.z, nc.x, nc.y};
@@ -868,6 +870,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         for(uint32_t i = 0; i < d->n_spheres; i++) {
             const float *sp = d->sph + 4 * static_cast<size_t>(i);
             spheres[i] = {sp[0], sp[1], sp[2], sp[3]};
+            tris[PT_TRI_QUADS * (static_cast<size_t>(d->n_triangles) + 1 + i)] = spheres[i]; // the record the traversal fetches (pt_types.h)
             sph_meta[i] = make_uint2(d->sph_material[i], s->sph_obj[i]);
         }
         std::vector<F4> pairs(4 * static_cast<size_t>(flat.n_pairs));
@@ -996,7 +999,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     dev.n_object_samples = static_cast<uint32_t>(object_sample_count);
     // LDS staging: a scene whose whole tree and triangle records fit in 24 KiB lives in LDS entirely (the path kernel's IN_LDS
     // variant); an LDS copy of only the top of a larger tree was measured in round 1 and does not pay.
-    const size_t small_bytes = static_cast<size_t>(n_pairs) * 64 + static_cast<size_t>(d->n_triangles) * 48;
+    const size_t small_bytes = static_cast<size_t>(n_pairs) * 64 + (static_cast<size_t>(d->n_triangles) + 1 + d->n_spheres) * 64;
     if(small_bytes <= 24 * 1024 && env_int("PT_LDS_SMALL", 1) != 0) {
         dev.n_lds_pairs = n_pairs;
         dev.n_lds_tris = d->n_triangles;
@@ -1163,6 +1166,38 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
         }
         return PT_OK;
     }
+}
+
+// Diagnostic, not part of include/pt_hip.h: walks n rays, `lanes_per_wave` of them per wavefront, with every traversal step stamped.
+// out[4 * i ..] = steps, cycles spent waiting for records (flags bit 1: stamped run), cycles of the whole walk, -; flags bit 0: prefetch (tools/step_timing.py).
+extern "C" int pt_debug_step_timing(pt_scene *s, const float *rays, size_t n, int lanes_per_wave, int flags, uint32_t *out) {
+    if(s == nullptr || rays == nullptr || out == nullptr || n == 0 || n > 0x3fffffULL || lanes_per_wave < 1 || lanes_per_wave > 64) {
+        return fail(PT_ERR_INVALID, "bad argument");
+    }
+    std::lock_guard<std::mutex> lock(s->render_mutex);
+    PT_HIP(hipSetDevice(s->device));
+    int rc = setup_path(s);
+    if(rc != PT_OK) {
+        return rc;
+    }
+    if(s->path_cfg.in_lds) {
+        return fail(PT_ERR_UNSUPPORTED, "step timing is for scenes in HBM");
+    }
+    const size_t waves = (n + static_cast<size_t>(lanes_per_wave) - 1) / static_cast<size_t>(lanes_per_wave);
+    const size_t threads = (waves + 3) / 4 * 256;
+    DevBuf<float> d_rays;
+    DevBuf<uint4> d_out;
+    DevBuf<uint2> d_spill;
+    PT_HIP(d_rays.ensure(6 * n));
+    PT_HIP(d_out.ensure(n));
+    PT_HIP(d_spill.ensure(threads * s->path_cfg.spill_depth));
+    hipStream_t st = s->stream;
+    PT_HIP(hipMemcpyAsync(d_rays.ptr, rays, 6 * n * sizeof(float), hipMemcpyHostToDevice, st));
+    pt_launch_steptime(st, s->dev, d_rays.ptr, static_cast<uint32_t>(n), static_cast<uint32_t>(lanes_per_wave), d_out.ptr, d_spill.ptr, s->path_cfg.spill_depth, flags);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipMemcpyAsync(out, d_out.ptr, n * sizeof(uint4), hipMemcpyDeviceToHost, st));
+    PT_HIP(hipStreamSynchronize(st));
+    return PT_OK;
 }
 
 // Diagnostic, not part of include/pt_hip.h: replays the rays the last render left in its rings (PT_RING_LOG_RAYS) through the traversal

@@ -26,7 +26,7 @@ struct PtBuildInput {
 // Device buffers the builder fills.  tris / tri_shade / spheres / sph_meta are allocated by the caller; pairs and dfs by the builder
 // (hipMalloc; ownership passes to the caller).
 struct PtBuildOutput {
-    float4 *tris = nullptr;      // 3 per triangle  (pt_types.h)
+    float4 *tris = nullptr;      // PT_TRI_QUADS per triangle  (pt_types.h)
     float4 *tri_shade = nullptr; // 8 per triangle
     float4 *spheres = nullptr;   // 1 per sphere
     uint2 *sph_meta = nullptr;   // 1 per sphere

@@ -139,10 +139,11 @@ __global__ void k_triangle_records(uint32_t n, const float *__restrict__ pos, co
         na[1] = nb[1] = nc[1] = cy * inv;
         na[2] = nb[2] = nc[2] = cz * inv;
     }
-    float4 *tr = tris + 3 * static_cast<size_t>(t);
+    float4 *tr = tris + PT_TRI_QUADS * static_cast<size_t>(t);
     tr[0] = r0;
     tr[1] = r1;
     tr[2] = r2;
+    tr[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 *sh = shade + 8 * static_cast<size_t>(t);
     sh[0] = r0;
     sh[1] = r1;
@@ -161,7 +162,7 @@ __global__ void k_triangle_records(uint32_t n, const float *__restrict__ pos, co
 
 // Sphere::getBoundingVolume (object.cpp:90-93)
 __global__ void k_sphere_records(uint32_t n, const float *__restrict__ sph, const uint32_t *__restrict__ material, const uint32_t *__restrict__ obj,
-                                 float4 *__restrict__ spheres, uint2 *__restrict__ meta, LeafArrays leaf) {
+                                 float4 *__restrict__ spheres, uint2 *__restrict__ meta, float4 *__restrict__ walk_records, LeafArrays leaf) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= n) {
         return;
@@ -171,6 +172,10 @@ __global__ void k_sphere_records(uint32_t n, const float *__restrict__ sph, cons
     const float r = sp[3];
     const uint32_t o = obj[i];
     spheres[i] = make_float4(c[0], c[1], c[2], r);
+    // the record the traversal fetches: behind the triangle records and their spare one (pt_types.h)
+    float4 *wr = walk_records + PT_TRI_QUADS * static_cast<size_t>(i);
+    wr[0] = make_float4(c[0], c[1], c[2], r);
+    wr[1] = wr[2] = wr[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     meta[i] = make_uint2(material[i], o);
     for(int k = 0; k < 3; k++) {
         leaf.lo[k][o] = c[k] - r;
@@ -683,7 +688,7 @@ hipError_t pt_build_scene_device(hipStream_t stream, const PtBuildInput &in, PtB
     }
     if(in.n_spheres > 0) {
         hipLaunchKernelGGL(k_sphere_records, grid_for(in.n_spheres), dim3(256), 0, stream, in.n_spheres, in.sph, in.sph_material, in.sph_obj, out.spheres, out.sph_meta,
-                           leaf);
+                           out.tris + PT_TRI_QUADS * (static_cast<size_t>(in.n_triangles) + 1), leaf);
     }
     PTB_TRY(hipGetLastError(), "leaf record kernels");
 

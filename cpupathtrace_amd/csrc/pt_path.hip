@@ -105,54 +105,38 @@ struct Walk {
 };
 
 // The traversal machinery of one lane: record arrays (LDS or HBM), the stack window in LDS and its HBM spill area.
+//
+// How a step is written matters as much as what it computes: a wavefront's step is a chain load -> slab tests -> decision -> address ->
+// load, and with few wavefronts per SIMD (a strong-scaling share, the tail of any job) its length IS the frame time, because a
+// stream's samples are sequential.  So the step below is straight-line code under WAVE-UNIFORM branches ("does any lane stand on an
+// inner node / a leaf / need to pop": one scalar branch each), with per-lane differences expressed as selects and one exec-masked
+// LDS store; records of both kinds have one stride (64 bytes), so the next record's address is one select and one shift-add.  The
+// version it replaces nested five divergent ifs per step and spent 109 scalar instructions per step on exec-mask bookkeeping
+// (profiles/r02_pmc_replay_kernel.txt).
 template<int STACK_LDS, bool IN_LDS>
 struct Tracer {
+    static_assert((STACK_LDS & (STACK_LDS - 1)) == 0, "the stack window is indexed with a mask");
     typedef typename RecPtr<IN_LDS>::type rec_ptr;
-    rec_ptr pairs, tris;
-    const float4 *spheres;
+    rec_ptr pairs, tris;  // 64-byte records both (pt_types.h)
+    uint32_t sphere_base; // record of sphere 0 in `tris`
+    bool prefetch;        // request the line of a node's inner children as soon as the node's record is there (see step)
     lds_u2_ptr stack_l; // this thread's column: entry e at stack_l[e * 256]
     glb_u2_ptr my_spill;
 
-    // The top STACK_LDS entries of a lane live in LDS (slot = index mod STACK_LDS), older ones in the lane's HBM spill area.
-    // Pushing onto a full window first moves the entry that is about to be overwritten to HBM; popping from a deep stack brings it
-    // back.  Walks rarely go deeper than the window, so the common path is one LDS access.
-    PT_D void push(uint32_t &sp, uint32_t ref, float entry_t) const {
-        const uint32_t slot = (sp % (uint32_t)STACK_LDS) * 256u;
-        if(sp >= (uint32_t)STACK_LDS) {
-            my_spill[sp - STACK_LDS] = stack_l[slot];
-        }
-        const u2v ev = {ref, __float_as_uint(entry_t)};
-        stack_l[slot] = ev;
-        sp++;
-    }
-    PT_D u2v pop(uint32_t &sp) const {
-        sp--;
-        const uint32_t slot = (sp % (uint32_t)STACK_LDS) * 256u;
-        const u2v e = stack_l[slot];
-        if(sp >= (uint32_t)STACK_LDS) {
-            stack_l[slot] = my_spill[sp - STACK_LDS];
-        }
-        return e;
-    }
-
-    // The 64-byte record a walk stands on, fetched as soon as the walk knows where it goes next: a node's pair of child boxes, a
-    // triangle (48 bytes; the fourth load reads into the next record -- the arrays are padded -- and is ignored) or a sphere (first word).
+    // The 64-byte record a walk stands on, requested as soon as the walk knows where it goes next: a node's pair of child boxes, a
+    // triangle, or a sphere's (origin, radius) -- the spheres' records stand behind the triangles', so there is no special case.
     struct Rec {
         f4v r0, r1, r2, r3;
+        uint32_t warm; // a word of the line requested ahead (never used: it keeps the request alive until the next step's wait)
     };
-    PT_D void fetch(const Walk &w, Rec &R) const {
-        const uint32_t idx = w.cur & PT_REF_INDEX;
-        if((w.cur & (PT_REF_LEAF | PT_REF_SPHERE)) == (PT_REF_LEAF | PT_REF_SPHERE)) {
-            const float4 s = spheres[idx];
-            R.r0 = (f4v){s.x, s.y, s.z, s.w};
-        }
-        else {
-            rec_ptr p = (w.cur & PT_REF_LEAF) ? tris + 3 * (size_t)idx : pairs + 4 * (size_t)idx;
-            R.r0 = p[0];
-            R.r1 = p[1];
-            R.r2 = p[2];
-            R.r3 = p[3];
-        }
+    PT_D void fetch(uint32_t cur, Rec &R) const {
+        const bool leaf = (cur & PT_REF_LEAF) != 0;
+        const uint32_t idx = (cur & PT_REF_INDEX) + ((cur & PT_REF_SPHERE) ? sphere_base : 0u); // (bit 30 is never set in an inner reference)
+        rec_ptr p = (leaf ? tris : pairs) + 4 * (size_t)idx;
+        R.r0 = p[0];
+        R.r1 = p[1];
+        R.r2 = p[2];
+        R.r3 = p[3];
     }
 
     // Start a walk: Scene::getIntersection tests the root box first (scene.cpp:211-219).
@@ -179,30 +163,38 @@ struct Tracer {
             const float t_root = slab_walk(ld3(root.lo), ld3(root.hi), w.o, w.inv);
             if(t_root >= 0.0f) {
                 w.cur = root.ref;
-                fetch(w, R);
+                fetch(w.cur, R);
             }
         }
     }
 
-    // One step of a walk standing on a node or a leaf (w.cur != PT_REF_NONE) whose record R was fetched when the walk got there;
-    // fetches the record of where the walk goes next.
-    PT_D void step(Walk &w, Rec &R, uint32_t &n_nodes, uint32_t &n_leaves) const {
-        advance(w, R, n_nodes, n_leaves);
-        if(w.cur != PT_REF_NONE) {
-            fetch(w, R);
-        }
-    }
-    // ... the same without the fetch
-    PT_D void advance(Walk &w, const Rec &R, uint32_t &n_nodes, uint32_t &n_leaves) const {
-        const bool is_leaf = (w.cur & PT_REF_LEAF) != 0;
+    // One step of the wavefront's walks.  `at_node`: this lane stands on an inner node whose record is in R; `at_leaf`: it stands on a
+    // leaf whose record is in R and the leaf code runs in this step; `any_node` / `any_leaf`: some lane of the wavefront does (uniform).
+    // Lanes with neither keep their walk and their record.  Every lane that moved requests the record of where it stands next.
+    PT_D void step(Walk &w, Rec &R, bool at_node, bool at_leaf, bool any_node, bool any_leaf, uint32_t &n_nodes, uint32_t &n_leaves) const {
         bool need_pop = false;
-        const float4 q0 = to_f4(R.r0), q1 = to_f4(R.r1), q2 = to_f4(R.r2), q3 = to_f4(R.r3);
-        if(!is_leaf) {
-            n_nodes++;
-            // AABB::getIntersection of both children (bounding_box.cpp:38-73): a box is hit iff t_max >= 0 and t_min <= t_max, its
-            // entry distance is max(t_min, 0) (0 = origin inside, :68-70).  impl::getChildIntersection (scene.cpp:113-146): a
-            // child is entered iff it is hit and its entry distance is below the pruning distance (entry >= 0 holds for every hit);
-            // with both entered the nearer one comes first -- on equal distances the RIGHT one (scene.cpp:120-121).
+        uint32_t cur = w.cur;
+        if(any_node) {
+            // AABB::getIntersection of both children (bounding_box.cpp:38-73): a box is hit iff t_max >= 0 and t_min <= t_max -- the same
+            // as max(t_min, 0) <= t_max -- and its entry distance is max(t_min, 0) (0 = origin inside, :68-70).
+            // impl::getChildIntersection (scene.cpp:113-146): a child is entered iff it is hit and its entry distance is below the pruning
+            // distance; with both entered the nearer one comes first -- on equal distances the RIGHT one (scene.cpp:120-121) -- and the
+            // other is parked with its entry distance.  (Lanes that do not stand on a node compute on whatever their registers hold and
+            // discard it.)
+            const f4v q0 = R.r0, q1 = R.r1, q2 = R.r2, q3 = R.r3;
+            if constexpr(!IN_LDS) {
+                asm volatile("" ::"v"(R.warm));
+                if(prefetch) {
+                    // The step is a chain record -> slab tests -> decision -> next record, and with few wavefronts per SIMD nothing hides the
+                    // second fetch behind the arithmetic.  The records of a node's two inner children share one aligned 128-byte line
+                    // (breadth-first slots, siblings on even / odd slots): one word of it is requested NOW, so that the record the decision
+                    // picks comes out of the cache.  (A node with two leaves asks for the tree's root: a cache hit.)
+                    const uint32_t l = __float_as_uint(q3.x), r = __float_as_uint(q3.y);
+                    const uint32_t inner = (l & PT_REF_LEAF) ? r : l;
+                    const uint32_t line = (at_node && !(inner & PT_REF_LEAF)) ? inner : 0u;
+                    R.warm = *reinterpret_cast<const uint32_t __attribute__((address_space(1))) *>((glb_f4_cptr)pairs + 4 * (size_t)line);
+                }
+            }
             const V3 o = w.o, inv = w.inv;
             const float l1 = (q0.x - o.x) * inv.x, l2 = (q0.w - o.x) * inv.x;
             const float l3 = (q0.y - o.y) * inv.y, l4 = (q1.x - o.y) * inv.y;
@@ -215,56 +207,89 @@ struct Tracer {
             const float r_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r1t, r2t), __builtin_fminf(r3t, r4t)), __builtin_fminf(r5t, r6t));
             const float r_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r1t, r2t), __builtin_fmaxf(r3t, r4t)), __builtin_fmaxf(r5t, r6t));
             const float left_t = __builtin_fmaxf(l_min, 0.0f), right_t = __builtin_fmaxf(r_min, 0.0f);
-            const bool go_left = l_max >= 0.0f && l_min <= l_max && left_t < w.t_max;
-            const bool go_right = r_max >= 0.0f && r_min <= r_max && right_t < w.t_max;
-            const uint32_t left_ref = __float_as_uint(q3.x);
-            const uint32_t right_ref = __float_as_uint(q3.y);
+            const float t_max = w.t_max;
+            const bool go_left = (left_t <= l_max) & (left_t < t_max);
+            const bool go_right = (right_t <= r_max) & (right_t < t_max);
             const bool left_first = left_t < right_t;
-            if(go_left && go_right) {
-                push(w.sp, left_first ? right_ref : left_ref, left_first ? right_t : left_t);
-                w.cur = left_first ? left_ref : right_ref;
+            const bool take_left = go_left & (!go_right | left_first);
+            const bool both = at_node & go_left & go_right;
+            const uint32_t left_ref = __float_as_uint(q3.x), right_ref = __float_as_uint(q3.y);
+            const uint32_t near_ref = take_left ? left_ref : right_ref;
+            // park the far child: the top STACK_LDS entries of a lane's stack live in LDS (slot = index mod STACK_LDS), older ones in the
+            // lane's HBM spill area; pushing onto a full window first moves the entry about to be overwritten (rare: one uniform branch)
+            const uint32_t sp = w.sp;
+            const uint32_t slot = (sp & (uint32_t)(STACK_LDS - 1)) * 256u;
+            if(__ballot(sp >= (uint32_t)STACK_LDS) != 0ULL) {
+                if(both & (sp >= (uint32_t)STACK_LDS)) {
+                    my_spill[sp - STACK_LDS] = stack_l[slot];
+                }
             }
-            else {
-                w.cur = go_left ? left_ref : right_ref;
+            if(both) {
+                const u2v ev = {take_left ? right_ref : left_ref, __float_as_uint(take_left ? right_t : left_t)};
+                stack_l[slot] = ev;
+                w.sp = sp + 1u;
             }
-            need_pop = !go_left && !go_right;
+            if(at_node) {
+                n_nodes++;
+            }
+            const bool entered = go_left | go_right;
+            cur = at_node ? (entered ? near_ref : PT_REF_NONE) : cur;
+            need_pop = at_node & !entered;
         }
-        else {
-            n_leaves++;
-            float t_leaf;
-            if(w.cur & PT_REF_SPHERE) {
-                t_leaf = sphere_intersect(v3(q0.x, q0.y, q0.z), q0.w, w.o, w.d);
-            }
-            else {
-                const TriRec tr = tri_unpack(q0, q1, q2);
-                t_leaf = tri_intersect(tr.a, tr.ab, tr.ac, (tr.obj_cull >> 31) != 0, w.o, w.d);
-            }
-            need_pop = true;
-            if(t_leaf >= 0.0f) {
-                if((w.dest & PT_DEST_SHADOW) && t_leaf < w.thr) {
-                    w.occluded = true; // worker.cpp:86: a hit closer than the light
-                    need_pop = false;
-                    w.cur = PT_REF_NONE;
+        if(any_leaf) {
+            if(at_leaf) {
+                // a leaf reports Object::getIntersection unconditionally (scene.cpp:105-109); among the non-negative hits the smallest wins and a
+                // later-visited leaf wins ties (scene.cpp:141-146); a shadow walk ends at its first hit below the threshold (worker.cpp:86)
+                n_leaves++;
+                const float4 q0 = to_f4(R.r0), q1 = to_f4(R.r1), q2 = to_f4(R.r2);
+                float t_leaf;
+                if(cur & PT_REF_SPHERE) {
+                    t_leaf = sphere_intersect(v3(q0.x, q0.y, q0.z), q0.w, w.o, w.d);
                 }
                 else {
-                    if(w.best_ref == PT_REF_NONE || !(w.best_t < t_leaf)) {
-                        w.best_t = t_leaf;
-                        w.best_ref = w.cur;
-                    }
-                    w.t_max = fmin_std(w.t_max, t_leaf);
+                    const TriRec tr = tri_unpack(q0, q1, q2);
+                    t_leaf = tri_intersect(tr.a, tr.ab, tr.ac, (tr.obj_cull >> 31) != 0, w.o, w.d);
                 }
+                need_pop = true;
+                if(t_leaf >= 0.0f) {
+                    if((w.dest & PT_DEST_SHADOW) && t_leaf < w.thr) {
+                        w.occluded = true;
+                        need_pop = false;
+                    }
+                    else {
+                        if(w.best_ref == PT_REF_NONE || !(w.best_t < t_leaf)) {
+                            w.best_t = t_leaf;
+                            w.best_ref = cur;
+                        }
+                        w.t_max = fmin_std(w.t_max, t_leaf);
+                    }
+                }
+                cur = PT_REF_NONE;
             }
         }
-        if(need_pop) {
-            // the first parked node whose entry distance is still below t_max
-            w.cur = PT_REF_NONE;
-            while(w.sp > 0) {
-                const u2v e = pop(w.sp);
-                if(__uint_as_float(e.y) < w.t_max) {
-                    w.cur = e.x;
-                    break;
+        // pop: the first parked node whose entry distance is still below t_max (scene.cpp:137: re-tested against the then-current distance)
+        if(__ballot(need_pop) != 0ULL) {
+            uint32_t sp = w.sp;
+            const float t_max = w.t_max;
+            while(__ballot(need_pop & (sp > 0u)) != 0ULL) {
+                if(need_pop & (sp > 0u)) {
+                    sp--;
+                    const uint32_t slot = (sp & (uint32_t)(STACK_LDS - 1)) * 256u;
+                    const u2v e = stack_l[slot];
+                    if(sp >= (uint32_t)STACK_LDS) {
+                        stack_l[slot] = my_spill[sp - STACK_LDS];
+                    }
+                    if(__uint_as_float(e.y) < t_max) {
+                        cur = e.x;
+                        need_pop = false;
+                    }
                 }
             }
+            w.sp = sp;
+        }
+        w.cur = cur;
+        if((at_node | at_leaf) & (cur != PT_REF_NONE)) {
+            fetch(cur, R);
         }
     }
 };
@@ -899,8 +924,8 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
         for(uint32_t i = tid; i < 4 * n_lds_pairs; i += 256) {
             lds_pairs[i] = src_pairs[i];
         }
-        for(uint32_t i = tid; i < 3 * n_lds_tris + 1; i += 256) { // + 1: the padding word the fourth load of the last triangle reads
-            lds_tris[i] = i < 3 * n_lds_tris ? src_tris[i] : make_float4(0, 0, 0, 0);
+        for(uint32_t i = tid; i < PT_TRI_QUADS * (n_lds_tris + 1 + A->sc.n_spheres); i += 256) { // triangles, the spare record, spheres (pt_types.h)
+            lds_tris[i] = src_tris[i];
         }
     }
     for(uint32_t i = lane; i < n_slots; i += 64) {
@@ -919,7 +944,8 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
         tr.pairs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)A->sc.pairs;
         tr.tris = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)A->sc.tris;
     }
-    tr.spheres = (const float4 *)(glb_f4_cptr)A->sc.spheres;
+    tr.sphere_base = A->sc.n_tris + 1u;
+    tr.prefetch = A->prefetch != 0;
     tr.stack_l = stack_l;
     tr.my_spill = (glb_u2_ptr)(A->spill + ((size_t)wave * 64 + lane) * A->spill_depth);
 
@@ -949,6 +975,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     w.occluded = false;
     typename Tracer<STACK_LDS, IN_LDS>::Rec rec;
     rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    rec.warm = 0;
     float4 win_o = make_float4(0, 0, 0, 0), win_d = make_float4(0, 0, 0, __uint_as_float(PT_DEST_NULL)); // the lane's ray of the ring's window
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0, n_samples = 0, n_vertices = 0;
     uint32_t w_steps = 0, w_passes = 0; // wave-level diagnostics (same value in every lane)
@@ -1039,8 +1066,9 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
             }
             // the record registers do not live across a shading pass: walks in progress fetch theirs again
             rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    rec.warm = 0;
             if(active && w.cur != PT_REF_NONE) {
-                tr.fetch(w, rec);
+                tr.fetch(w.cur, rec);
             }
         }
 
@@ -1133,9 +1161,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                 }
                 const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
                 w_steps++;
-                if(standing && (!at_leaf || do_leaves)) {
-                    tr.step(w, rec, n_nodes, n_leaves);
-                }
+                tr.step(w, rec, standing && !at_leaf, at_leaf && do_leaves, node_mask != 0ULL, do_leaves && leaf_mask != 0ULL, n_nodes, n_leaves);
             }
 #ifdef PT_PATH_TIMING
             t_burst += __builtin_amdgcn_s_memtime() - t_b0;
@@ -1177,7 +1203,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
 // Scene::getIntersection for a batch of rays: one walk per lane, the same traversal machinery
 template<int STACK_LDS, bool IN_LDS>
 __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const float *__restrict__ rays6, uint32_t n, uint2 *__restrict__ out, uint2 *__restrict__ spill,
-                                                         uint32_t spill_depth) {
+                                                         uint32_t spill_depth, int prefetch) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     lds_u2_ptr stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(lds_raw) + tid;
@@ -1187,8 +1213,8 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
         for(uint32_t i = tid; i < 4 * sc.n_lds_pairs; i += 256) {
             lds_pairs[i] = sc.pairs[i];
         }
-        for(uint32_t i = tid; i < 3 * sc.n_lds_tris + 1; i += 256) {
-            lds_tris[i] = i < 3 * sc.n_lds_tris ? sc.tris[i] : make_float4(0, 0, 0, 0);
+        for(uint32_t i = tid; i < PT_TRI_QUADS * (sc.n_lds_tris + 1 + sc.n_spheres); i += 256) {
+            lds_tris[i] = sc.tris[i];
         }
         __syncthreads();
     }
@@ -1201,7 +1227,8 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
         tr.pairs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.pairs;
         tr.tris = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.tris;
     }
-    tr.spheres = sc.spheres;
+    tr.sphere_base = sc.n_tris + 1u;
+    tr.prefetch = prefetch != 0;
     tr.stack_l = stack_l;
     const size_t gid = (size_t)blockIdx.x * 256 + tid;
     tr.my_spill = (glb_u2_ptr)(spill + gid * spill_depth);
@@ -1212,6 +1239,7 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
     Walk w;
     typename Tracer<STACK_LDS, IN_LDS>::Rec rec;
     rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    rec.warm = 0;
     RootBox root;
     root.ref = sc.root_ref;
     for(int k = 0; k < 3; k++) {
@@ -1220,10 +1248,74 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
     }
     tr.start(w, rec, root, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
     uint32_t n_nodes = 0, n_leaves = 0;
-    while(w.cur != PT_REF_NONE) {
-        tr.step(w, rec, n_nodes, n_leaves);
+    for(;;) {
+        const bool standing = w.cur != PT_REF_NONE, at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
+        const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
+        if((leaf_mask | node_mask) == 0ULL) {
+            break;
+        }
+        tr.step(w, rec, standing && !at_leaf, at_leaf, node_mask != 0ULL, leaf_mask != 0ULL, n_nodes, n_leaves);
     }
     out[gid] = make_uint2(__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref);
+}
+
+// ---- diagnostic: where the cycles of a traversal step go -------------------------------------------------------------------------------
+// One walk per lane as in pt_closest_kernel, but only the first `lanes_per_wave` lanes of every wavefront get a ray, and every step is
+// stamped (s_memtime): cycles spent waiting for the record that was requested at the end of the previous step, and everything else.
+// out[ray] = (steps, cycles waiting for records, cycles of the whole walk, cycles of two back-to-back stamps = the stamps' own price).
+template<int STACK_LDS, bool STAMP>
+__global__ __launch_bounds__(256) void pt_steptime_kernel(PtDevScene sc, const float *__restrict__ rays6, uint32_t n, uint32_t lanes_per_wave, uint4 *__restrict__ out,
+                                                          uint2 *__restrict__ spill, uint32_t spill_depth, int prefetch) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)tid & 63u;
+    const uint32_t wave = blockIdx.x * 4u + ((uint32_t)tid >> 6);
+    Tracer<STACK_LDS, false> tr;
+    tr.pairs = (glb_f4_cptr)sc.pairs;
+    tr.tris = (glb_f4_cptr)sc.tris;
+    tr.sphere_base = sc.n_tris + 1u;
+    tr.prefetch = prefetch != 0;
+    tr.stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(lds_raw) + tid;
+    const size_t gid = (size_t)blockIdx.x * 256 + tid;
+    tr.my_spill = (glb_u2_ptr)(spill + gid * spill_depth);
+    const uint32_t ray = wave * lanes_per_wave + lane;
+    if(lane >= lanes_per_wave || ray >= n) {
+        return;
+    }
+    const float *r = rays6 + 6 * (size_t)ray;
+    Walk w;
+    typename Tracer<STACK_LDS, false>::Rec rec;
+    rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    rec.warm = 0;
+    RootBox root;
+    root.ref = sc.root_ref;
+    for(int k = 0; k < 3; k++) {
+        root.lo[k] = sc.root_lo[k];
+        root.hi[k] = sc.root_hi[k];
+    }
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_again = __builtin_amdgcn_s_memtime();
+    tr.start(w, rec, root, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
+    uint32_t n_nodes = 0, n_leaves = 0, steps = 0;
+    unsigned long long waiting = 0;
+    for(;;) {
+        const bool standing = w.cur != PT_REF_NONE, at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
+        const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
+        if((leaf_mask | node_mask) == 0ULL) {
+            break;
+        }
+        if(STAMP) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            waiting += t2 - t1;
+        }
+        steps += standing ? 1u : 0u;
+        tr.step(w, rec, standing && !at_leaf, at_leaf, node_mask != 0ULL, leaf_mask != 0ULL, n_nodes, n_leaves);
+    }
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    out[ray] = make_uint4(steps, (uint32_t)waiting, (uint32_t)(t_end - t_begin), (uint32_t)(t_again - t_begin));
 }
 
 // ---- diagnostic: the traversal alone on the rays of a finished render ----------------------------------------------------------------
@@ -1235,7 +1327,7 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
 template<int STACK_LDS, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, PtLocalQueue Q, uint32_t n_logs, uint32_t parts, int refill_idle, int burst_steps,
                                                                 int leaf_min, uint2 *__restrict__ spill, uint32_t spill_depth,
-                                                                unsigned long long *__restrict__ out) {
+                                                                unsigned long long *__restrict__ out, int prefetch) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
@@ -1246,7 +1338,8 @@ __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, Pt
     Tracer<STACK_LDS, false> tr;
     tr.pairs = (glb_f4_cptr)sc.pairs;
     tr.tris = (glb_f4_cptr)sc.tris;
-    tr.spheres = sc.spheres;
+    tr.sphere_base = sc.n_tris + 1u;
+    tr.prefetch = prefetch != 0;
     tr.stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(lds_raw) + tid;
     tr.my_spill = (glb_u2_ptr)(spill + ((size_t)wave * 64 + lane) * spill_depth);
     RootBox root;
@@ -1286,6 +1379,7 @@ __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, Pt
     w.occluded = false;
     typename Tracer<STACK_LDS, false>::Rec rec;
     rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    rec.warm = 0;
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, checksum = 0, w_steps = 0;
     for(;;) {
         if(active && w.cur == PT_REF_NONE) {
@@ -1327,9 +1421,7 @@ __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, Pt
             }
             const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
             w_steps++;
-            if(standing && (!at_leaf || do_leaves)) {
-                tr.step(w, rec, n_nodes, n_leaves);
-            }
+            tr.step(w, rec, standing && !at_leaf, at_leaf && do_leaves, node_mask != 0ULL, do_leaves && leaf_mask != 0ULL, n_nodes, n_leaves);
         }
     }
     for(int off = 32; off > 0; off >>= 1) {
@@ -1357,7 +1449,7 @@ int launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueu
     }
     const uint32_t waves = n_logs * parts;
     hipLaunchKernelGGL((pt_replay_kernel<STACK_LDS, WAVES>), dim3((waves + 3) / 4), dim3(256), lds, stream, scene, Q, n_logs, parts, cfg.refill_idle,
-                       cfg.burst_steps, cfg.leaf_min, spill, cfg.spill_depth, out);
+                       cfg.burst_steps, cfg.leaf_min, spill, cfg.spill_depth, out, cfg.prefetch);
     return blocks;
 }
 
@@ -1375,8 +1467,8 @@ int occupancy(size_t lds_bytes) {
 
 template<int STACK_LDS, bool IN_LDS>
 void launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg) {
-    const size_t lds = (size_t)STACK_LDS * 256 * sizeof(uint2) + (IN_LDS ? (size_t)scene.n_lds_pairs * 64 + (size_t)scene.n_lds_tris * 48 + 16 : 0);
-    hipLaunchKernelGGL((pt_closest_kernel<STACK_LDS, IN_LDS>), dim3((n + 255) / 256), dim3(256), lds, stream, scene, rays6, n, out, cfg.spill, cfg.spill_depth);
+    const size_t lds = (size_t)STACK_LDS * 256 * sizeof(uint2) + (IN_LDS ? (size_t)scene.n_lds_pairs * 64 + ((size_t)scene.n_lds_tris + 1 + scene.n_spheres) * 64 : 0);
+    hipLaunchKernelGGL((pt_closest_kernel<STACK_LDS, IN_LDS>), dim3((n + 255) / 256), dim3(256), lds, stream, scene, rays6, n, out, cfg.spill, cfg.spill_depth, cfg.prefetch);
 }
 
 } // namespace
@@ -1417,6 +1509,7 @@ void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCame
     a.burst_steps = cfg.burst_steps;
     a.leaf_min = cfg.leaf_min;
     a.ready_shift = cfg.ready_shift;
+    a.prefetch = cfg.prefetch;
     a.spill = cfg.spill;
     a.spill_depth = cfg.spill_depth;
     a.save_stride = (uint32_t)cfg.grid * 256u;
@@ -1426,6 +1519,16 @@ void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCame
     a.wave_counters = cfg.wave_counters;
     (void)hipMemcpyAsync(d_args, host_args, sizeof(PtPathArgs), hipMemcpyHostToDevice, stream);
     PT_DISPATCH(launch_path, cfg, stream, cfg, d_args);
+}
+
+void pt_launch_steptime(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint32_t lanes_per_wave, uint4 *out, uint2 *spill, uint32_t spill_depth, int prefetch) {
+    const uint32_t waves = (n + lanes_per_wave - 1) / lanes_per_wave;
+    if(prefetch & 2) { // bit 1: stamp the waits (each stamp is a scalar memory round trip of its own: the totals of such a run are inflated)
+        hipLaunchKernelGGL((pt_steptime_kernel<8, true>), dim3((waves + 3) / 4), dim3(256), (size_t)8 * 256 * sizeof(uint2), stream, scene, rays6, n, lanes_per_wave, out, spill, spill_depth, prefetch & 1);
+    }
+    else {
+        hipLaunchKernelGGL((pt_steptime_kernel<8, false>), dim3((waves + 3) / 4), dim3(256), (size_t)8 * 256 * sizeof(uint2), stream, scene, rays6, n, lanes_per_wave, out, spill, spill_depth, prefetch & 1);
+    }
 }
 
 void pt_launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg) {
@@ -1446,8 +1549,8 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
     }
 }
 
-size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_tris) {
-    const size_t scene = (n_lds_pairs != 0 || n_lds_tris != 0) ? (size_t)n_lds_pairs * 64 + (size_t)n_lds_tris * 48 + 16 : 0;
+size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
+    const size_t scene = ((size_t)n_lds_pairs + n_lds_leaf_records) * 64;
     return (size_t)stack_lds * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + sizeof(uint32_t)) + PT_LDS_TABLE_BYTES + scene;
 }
 

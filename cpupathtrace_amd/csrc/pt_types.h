@@ -8,8 +8,10 @@
 //                                     q1 = (L.hi.y, L.hi.z, R.lo.x, R.lo.y)
 //                                     q2 = (R.lo.z, R.hi.x, R.hi.y, R.hi.z)
 //                                     q3 = (bits L.ref, bits R.ref, 0, 0)
-//   tris      float4[3 * n_tris + 1] 48-byte record per triangle (+ one padding word: a traversal step reads 64 bytes) for Moeller-Trumbore and the barycentric normal:
-//                                     q0 = (a.x, a.y, a.z, ab.x)  q1 = (ab.y, ab.z, ac.x, ac.y)  q2 = (ac.z, bits material, bits (obj | cull << 31), 0)
+//   tris      float4[4 * (n_tris + 1 + n_spheres)]  the LEAF records of the traversal, 64 bytes each (the stride of a pair record: a walk fetches
+//                                   the record it stands on with one address computation whatever it is).  Triangle t at record t, for Moeller-Trumbore:
+//                                     q0 = (a.x, a.y, a.z, ab.x)  q1 = (ab.y, ab.z, ac.x, ac.y)  q2 = (ac.z, bits material, bits (obj | cull << 31), 0)  q3 = 0
+//                                   then one spare record, then sphere i at record n_tris + 1 + i: q0 = (origin.xyz, radius), rest 0
 //                                   ab = b - a and ac = c - a are the fp32 differences the reference forms on every call
 //                                   (src/scene/object.cpp:127-128,149-150), formed once on the host.
 //   tri_shade float4[8 * n_tris]    128-byte (one HBM line) record per triangle for the shading kernel: the three words of `tris`
@@ -34,6 +36,7 @@
 #define PT_REF_INDEX 0x3fffffffu
 #define PT_REF_NONE 0xffffffffu /* also: a leaf holding the NullObject of an empty scene */
 
+#define PT_TRI_QUADS 4      /* float4 per record of `tris` */
 #define PT_MAX_NEE 8        /* light samples per path vertex: point lights + object samples */
 #define PT_MAX_CANDIDATES 8 /* closed candidates of the per-pixel estimator (worker.cpp:183-185) */
 #define PT_MAX_DEPTH 128    /* deepest supported BVH */

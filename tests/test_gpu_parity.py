@@ -551,3 +551,63 @@ def test_unusual_options_vs_oracle(sset, oracle_lib, name, w, h, mn, mx, eps):
         assert_bits_equal(after, states_after, "engine states after the pixels")
     finally:
         scene.close()
+
+
+def _pixel_job(gpu, chk_scene, cam, opt, seed=2468):
+    """One processJob on the device (with its work counters) and the same pixels through the oracle (with its counters)."""
+    w, h = opt["image_width"], opt["image_height"]
+    img, st = gpu.process_job(cam, opt, base_seed=seed, want_stats=True)
+    ys, xs = np.mgrid[0:h, 0:w]
+    xs, ys = xs.ravel().astype(np.int32), ys.ravel().astype(np.int32)
+    states = np.array([binding.seed_to_state(binding.pixel_seed(seed, int(x), int(y))) for x, y in zip(xs, ys)], np.uint64)
+    chk_scene.counters_reset()
+    want, _ = chk_scene.render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=8)
+    assert_bits_equal(img, want, "frame")
+    return st, chk_scene.counters()
+
+
+@pytest.mark.parametrize("name,w,h,mn,mx", [("box", 40, 40, 8, 8), ("meshbox", 32, 32, 8, 8), ("cornell", 32, 32, 4, 24)])
+def test_kernel_work_counters_vs_oracle(gpu_scenes, sset, oracle_lib, name, w, h, mn, mx):
+    """The counters that feed bench.py's roofline (pt_stats: samples, vertices, rays, node visits, leaf tests -- counted by the kernel in
+    per-wave registers) against the oracle's own counters for the same pixels.  Samples, path vertices and extension rays (camera +
+    bounce) must be EQUAL.  Shadow rays may only be fewer: the kernel traces none where the reference's result does not depend on it
+    (specular BSDFs: p = 0 for synthetic pairs, worker.cpp:92; contributions of +-0; thresholds <= 0), and a shadow walk stops at its
+    first occluder, so slab and leaf tests are bounded by the oracle's, never above."""
+    desc, cam = sset[name]
+    if name == "cornell":
+        cam = dict(cam, aspect_ratio=-float(np.float32(w) / np.float32(h)))
+    st, c = _pixel_job(gpu_scenes(name), oracle_lib.scene_create(desc), cam, scenes.options(w, h, mn, mx))
+    assert st["samples"] == c["samples"] > 0
+    assert st["vertices"] == c["vertices"] > 0
+    assert st["rays_traced"] - st["shadow_rays_traced"] == c["scene_queries"] - c["shadow_rays"], "extension rays (camera + bounce)"
+    assert 0 < st["shadow_rays_traced"] <= c["shadow_rays"]
+    assert st["rays_traced"] <= c["scene_queries"]
+    assert 2 * st["node_visits"] + st["rays_traced"] <= c["aabb_tests"], "two slab tests per inner node + the root test of every ray"
+    assert st["leaf_tests"] <= c["tri_tests"] + c["sphere_tests"]
+    # ... and not far below: the shortcuts only ever drop shadow rays
+    assert 2 * st["node_visits"] + st["rays_traced"] >= 0.3 * c["aabb_tests"]
+
+
+def test_kernel_work_counters_exact_without_lights(oracle_lib):
+    """No emitter, no point light -> no shadow rays at all: every counter of the kernel equals the oracle's (each walk visits exactly the
+    nodes and leaves the reference's recursion visits)."""
+    sb = scenes.SceneBuilder()
+    sb.triangles(scenes.make_box((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), sb.material((0.8, 0.7, 0.6, 1.0)))
+    sb.sphere((0.3, -0.6, 0.2), 0.4, sb.material((1, 1, 1, 1), 1.5, bsdf=scenes.BSDF_GLASS))
+    sb.sphere((-0.4, -0.7, -0.2), 0.3, sb.material((1, 1, 1, 1), bsdf=scenes.BSDF_MIRROR))
+    rng = np.random.default_rng(9)
+    sb.triangles(rng.uniform(-0.9, 0.9, (1500, 1, 3)).astype(np.float32) + rng.uniform(-0.08, 0.08, (1500, 3, 3)).astype(np.float32), sb.material((0.5, 0.9, 0.5, 1.0)))
+    desc = sb.build()
+    cam = scenes.camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, -1.0)
+    for mode in ("host", "device"):
+        scene = _scene_with(mode, desc)
+        try:
+            st, c = _pixel_job(scene, oracle_lib.scene_create(desc), cam, scenes.options(48, 48, 6, 6))
+        finally:
+            scene.close()
+        assert c["shadow_rays"] == 0 and st["shadow_rays_traced"] == 0
+        assert st["samples"] == c["samples"] == 48 * 48 * 6
+        assert st["vertices"] == c["vertices"] > 0
+        assert st["rays_traced"] == c["scene_queries"]
+        assert 2 * st["node_visits"] + st["rays_traced"] == c["aabb_tests"]
+        assert st["leaf_tests"] == c["tri_tests"] + c["sphere_tests"]

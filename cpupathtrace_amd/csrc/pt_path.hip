@@ -46,6 +46,7 @@ using namespace ptd;
 namespace {
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 typedef const f4v __attribute__((address_space(3))) *lds_f4_cptr;
 typedef const f4v __attribute__((address_space(1))) *glb_f4_cptr;
@@ -94,6 +95,19 @@ struct RootBox {
 // One walk (one ray) in a lane.
 struct Walk {
     V3 o, d, inv;
+#ifdef PT_PACKED_SLAB
+    f2v o_xy, o_zx, o_yz, i_xy, i_zx, i_yz; // origin and inverse direction again, as the register pairs of the packed slab arithmetic
+    PT_D void pack() {
+        o_xy = (f2v){o.x, o.y};
+        o_zx = (f2v){o.z, o.x};
+        o_yz = (f2v){o.y, o.z};
+        i_xy = (f2v){inv.x, inv.y};
+        i_zx = (f2v){inv.z, inv.x};
+        i_yz = (f2v){inv.y, inv.z};
+    }
+#else
+    PT_D void pack() {}
+#endif
     float thr;       // shadow threshold |to_light| - epsilon (worker.cpp:86)
     uint32_t dest;   // destination word of the ray
     float best_t;
@@ -146,6 +160,7 @@ struct Tracer {
         w.thr = ro.w;
         w.dest = __float_as_uint(rd.w);
         w.inv = slab_inverse(w.d);
+        w.pack();
         w.best_ref = PT_REF_NONE;
         w.best_t = -1.0f;
         // A shadow ray is a closest-hit query like any other in the reference (worker.cpp:83-86) and must be pruned like one: starting it
@@ -168,13 +183,23 @@ struct Tracer {
         }
     }
 
-    // One step of the wavefront's walks.  `at_node`: this lane stands on an inner node whose record is in R; `at_leaf`: it stands on a
-    // leaf whose record is in R and the leaf code runs in this step; `any_node` / `any_leaf`: some lane of the wavefront does (uniform).
-    // Lanes with neither keep their walk and their record.  Every lane that moved requests the record of where it stands next.
-    PT_D void step(Walk &w, Rec &R, bool at_node, bool at_leaf, bool any_node, bool any_leaf, uint32_t &n_nodes, uint32_t &n_leaves) const {
-        bool need_pop = false;
+    // One step of the wavefront's walks.  `node_mask`: the lanes that stand on an inner node whose record is in R; `leaf_mask`: the lanes that
+    // stand on a leaf whose record is in R and whose leaf code runs in this step.  Lanes in neither keep their walk and their record.
+    // Every lane that moved requests the record of where it stands next.  n_nodes / n_leaves count visits for the whole wavefront
+    // (the same value in every lane).
+    //
+    // The decisions are taken on WAVE MASKS in scalar registers (v_cmp into an SGPR pair, s_and / s_or on it, the mask as the condition of
+    // a v_cndmask): no lane-boolean is ever materialised in a vector register and nothing is exec-masked on the common path.
+    static PT_D unsigned long long f_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5); }  // ordered <=
+    static PT_D unsigned long long f_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }  // ordered <
+    static PT_D unsigned long long u_ge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35); }
+    static PT_D unsigned long long u_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
+    static PT_D bool lane_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
+    PT_D void step(Walk &w, Rec &R, unsigned long long node_mask, unsigned long long leaf_mask, uint32_t &n_nodes, uint32_t &n_leaves) const {
+        unsigned long long pop_mask = 0ULL; // lanes that go on popping in the loop at the end
         uint32_t cur = w.cur;
-        if(any_node) {
+        if(node_mask != 0ULL) {
             // AABB::getIntersection of both children (bounding_box.cpp:38-73): a box is hit iff t_max >= 0 and t_min <= t_max -- the same
             // as max(t_min, 0) <= t_max -- and its entry distance is max(t_min, 0) (0 = origin inside, :68-70).
             // impl::getChildIntersection (scene.cpp:113-146): a child is entered iff it is hit and its entry distance is below the pruning
@@ -191,10 +216,27 @@ struct Tracer {
                     // picks comes out of the cache.  (A node with two leaves asks for the tree's root: a cache hit.)
                     const uint32_t l = __float_as_uint(q3.x), r = __float_as_uint(q3.y);
                     const uint32_t inner = (l & PT_REF_LEAF) ? r : l;
-                    const uint32_t line = (at_node && !(inner & PT_REF_LEAF)) ? inner : 0u;
+                    const uint32_t line = (lane_of(node_mask) && !(inner & PT_REF_LEAF)) ? inner : 0u;
                     R.warm = *reinterpret_cast<const uint32_t __attribute__((address_space(1))) *>((glb_f4_cptr)pairs + 4 * (size_t)line);
                 }
             }
+            const uint32_t sp = w.sp;
+            const float t_max = w.t_max;
+            // the top entry of the lane's stack, read ahead of the arithmetic that decides whether it is needed (see below; a lane with an
+            // empty stack reads a slot nobody looks at)
+            const u2v top = stack_l[((sp - 1u) & (uint32_t)(STACK_LDS - 1)) * 256u];
+#ifdef PT_PACKED_SLAB
+            // the same twelve differences and products as below, two per instruction (v_pk_add_f32 with a negated operand is the IEEE
+            // subtraction, v_pk_mul_f32 the IEEE product: nothing is fused)
+            const f2v a0 = ((f2v){q0.x, q0.y} - w.o_xy) * w.i_xy; // L.lo.x, L.lo.y
+            const f2v a1 = ((f2v){q0.z, q0.w} - w.o_zx) * w.i_zx; // L.lo.z, L.hi.x
+            const f2v a2 = ((f2v){q1.x, q1.y} - w.o_yz) * w.i_yz; // L.hi.y, L.hi.z
+            const f2v a3 = ((f2v){q1.z, q1.w} - w.o_xy) * w.i_xy; // R.lo.x, R.lo.y
+            const f2v a4 = ((f2v){q2.x, q2.y} - w.o_zx) * w.i_zx; // R.lo.z, R.hi.x
+            const f2v a5 = ((f2v){q2.z, q2.w} - w.o_yz) * w.i_yz; // R.hi.y, R.hi.z
+            const float l1 = a0.x, l2 = a1.y, l3 = a0.y, l4 = a2.x, l5 = a1.x, l6 = a2.y;
+            const float r1t = a3.x, r2t = a4.y, r3t = a3.y, r4t = a5.x, r5t = a4.x, r6t = a5.y;
+#else
             const V3 o = w.o, inv = w.inv;
             const float l1 = (q0.x - o.x) * inv.x, l2 = (q0.w - o.x) * inv.x;
             const float l3 = (q0.y - o.y) * inv.y, l4 = (q1.x - o.y) * inv.y;
@@ -202,45 +244,59 @@ struct Tracer {
             const float r1t = (q1.z - o.x) * inv.x, r2t = (q2.y - o.x) * inv.x;
             const float r3t = (q1.w - o.y) * inv.y, r4t = (q2.z - o.y) * inv.y;
             const float r5t = (q2.x - o.z) * inv.z, r6t = (q2.w - o.z) * inv.z;
+#endif
             const float l_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(l1, l2), __builtin_fminf(l3, l4)), __builtin_fminf(l5, l6));
             const float l_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(l1, l2), __builtin_fmaxf(l3, l4)), __builtin_fmaxf(l5, l6));
             const float r_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r1t, r2t), __builtin_fminf(r3t, r4t)), __builtin_fminf(r5t, r6t));
             const float r_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r1t, r2t), __builtin_fmaxf(r3t, r4t)), __builtin_fmaxf(r5t, r6t));
             const float left_t = __builtin_fmaxf(l_min, 0.0f), right_t = __builtin_fmaxf(r_min, 0.0f);
-            const float t_max = w.t_max;
-            const bool go_left = (left_t <= l_max) & (left_t < t_max);
-            const bool go_right = (right_t <= r_max) & (right_t < t_max);
-            const bool left_first = left_t < right_t;
-            const bool take_left = go_left & (!go_right | left_first);
-            const bool both = at_node & go_left & go_right;
+            const unsigned long long go_left = f_le(left_t, l_max) & f_lt(left_t, t_max);
+            const unsigned long long go_right = f_le(right_t, r_max) & f_lt(right_t, t_max);
+            const unsigned long long take_left_m = go_left & (~go_right | f_lt(left_t, right_t));
+            const unsigned long long both_m = go_left & go_right & node_mask;
+            const unsigned long long entered_m = go_left | go_right;
+            const bool take_left = lane_of(take_left_m);
             const uint32_t left_ref = __float_as_uint(q3.x), right_ref = __float_as_uint(q3.y);
             const uint32_t near_ref = take_left ? left_ref : right_ref;
+            const u2v far = {take_left ? right_ref : left_ref, __float_as_uint(take_left ? right_t : left_t)};
             // park the far child: the top STACK_LDS entries of a lane's stack live in LDS (slot = index mod STACK_LDS), older ones in the
-            // lane's HBM spill area; pushing onto a full window first moves the entry about to be overwritten (rare: one uniform branch)
-            const uint32_t sp = w.sp;
+            // lane's HBM spill area
             const uint32_t slot = (sp & (uint32_t)(STACK_LDS - 1)) * 256u;
-            if(__ballot(sp >= (uint32_t)STACK_LDS) != 0ULL) {
+            n_nodes += (uint32_t)__popcll(node_mask);
+            if(u_ge(sp, (uint32_t)STACK_LDS) == 0ULL) {
+                // No lane's stack reaches beyond its window (the common case, one scalar branch).  The far child is written ABOVE the top
+                // of the stack by every lane -- it only becomes an entry where the stack pointer moves -- and the top entry is read by
+                // every lane, so that a lane that entered no child continues with it at once (the first pop of the recursion's return,
+                // scene.cpp:137) without a second trip to LDS; only a popped entry that fails the distance test sends the lane into the
+                // loop below.
+                stack_l[slot] = far;
+                const unsigned long long pop1_m = node_mask & ~entered_m & u_ne(sp, 0u);
+                const unsigned long long popped_m = pop1_m & f_lt(__uint_as_float(top.y), t_max);
+                const uint32_t next = lane_of(entered_m) ? near_ref : (lane_of(popped_m) ? top.x : PT_REF_NONE);
+                cur = lane_of(node_mask) ? next : cur;
+                w.sp = sp + (lane_of(both_m) ? 1u : 0u) - (lane_of(pop1_m) ? 1u : 0u);
+                pop_mask = pop1_m & ~popped_m;
+            }
+            else {
+                // pushing onto a full window first moves the entry about to be overwritten to the spill area
+                const bool both = lane_of(both_m);
                 if(both & (sp >= (uint32_t)STACK_LDS)) {
                     my_spill[sp - STACK_LDS] = stack_l[slot];
                 }
+                if(both) {
+                    stack_l[slot] = far;
+                    w.sp = sp + 1u;
+                }
+                cur = lane_of(node_mask) ? (lane_of(entered_m) ? near_ref : PT_REF_NONE) : cur;
+                pop_mask = node_mask & ~entered_m;
             }
-            if(both) {
-                const u2v ev = {take_left ? right_ref : left_ref, __float_as_uint(take_left ? right_t : left_t)};
-                stack_l[slot] = ev;
-                w.sp = sp + 1u;
-            }
-            if(at_node) {
-                n_nodes++;
-            }
-            const bool entered = go_left | go_right;
-            cur = at_node ? (entered ? near_ref : PT_REF_NONE) : cur;
-            need_pop = at_node & !entered;
         }
-        if(any_leaf) {
-            if(at_leaf) {
+        if(leaf_mask != 0ULL) {
+            n_leaves += (uint32_t)__popcll(leaf_mask);
+            bool leaf_pop = false;
+            if(lane_of(leaf_mask)) {
                 // a leaf reports Object::getIntersection unconditionally (scene.cpp:105-109); among the non-negative hits the smallest wins and a
                 // later-visited leaf wins ties (scene.cpp:141-146); a shadow walk ends at its first hit below the threshold (worker.cpp:86)
-                n_leaves++;
                 const float4 q0 = to_f4(R.r0), q1 = to_f4(R.r1), q2 = to_f4(R.r2);
                 float t_leaf;
                 if(cur & PT_REF_SPHERE) {
@@ -250,11 +306,11 @@ struct Tracer {
                     const TriRec tr = tri_unpack(q0, q1, q2);
                     t_leaf = tri_intersect(tr.a, tr.ab, tr.ac, (tr.obj_cull >> 31) != 0, w.o, w.d);
                 }
-                need_pop = true;
+                leaf_pop = true;
                 if(t_leaf >= 0.0f) {
                     if((w.dest & PT_DEST_SHADOW) && t_leaf < w.thr) {
                         w.occluded = true;
-                        need_pop = false;
+                        leaf_pop = false;
                     }
                     else {
                         if(w.best_ref == PT_REF_NONE || !(w.best_t < t_leaf)) {
@@ -266,9 +322,11 @@ struct Tracer {
                 }
                 cur = PT_REF_NONE;
             }
+            pop_mask |= __ballot(leaf_pop);
         }
         // pop: the first parked node whose entry distance is still below t_max (scene.cpp:137: re-tested against the then-current distance)
-        if(__ballot(need_pop) != 0ULL) {
+        if(pop_mask != 0ULL) {
+            bool need_pop = lane_of(pop_mask);
             uint32_t sp = w.sp;
             const float t_max = w.t_max;
             while(__ballot(need_pop & (sp > 0u)) != 0ULL) {
@@ -288,7 +346,7 @@ struct Tracer {
             w.sp = sp;
         }
         w.cur = cur;
-        if((at_node | at_leaf) & (cur != PT_REF_NONE)) {
+        if(lane_of(node_mask | leaf_mask) & (cur != PT_REF_NONE)) {
             fetch(cur, R);
         }
     }
@@ -965,6 +1023,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     w.o = v3(0, 0, 0);
     w.d = v3(0, 0, 1);
     w.inv = v3(0, 0, 0);
+    w.pack();
     w.thr = 0.0f;
     w.dest = 0;
     w.best_t = 0.0f;
@@ -1038,6 +1097,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                 w.o = v3(__uint_as_float(sv[0 * st]), __uint_as_float(sv[1 * st]), __uint_as_float(sv[2 * st]));
                 w.d = v3(__uint_as_float(sv[3 * st]), __uint_as_float(sv[4 * st]), __uint_as_float(sv[5 * st]));
                 w.inv = slab_inverse(w.d);
+                w.pack();
                 w.thr = __uint_as_float(sv[6 * st]);
                 w.dest = sv[7 * st];
                 w.best_t = __uint_as_float(sv[8 * st]);
@@ -1153,15 +1213,15 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
 #endif
 #pragma unroll 1
             for(int burst = 0; burst < burst_steps; burst++) {
-                const bool standing = active && w.cur != PT_REF_NONE;
-                const bool at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
-                const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
+                // (a reference with bit 31 set is a leaf -- or PT_REF_NONE, which is excluded first)
+                const unsigned long long standing_mask = __ballot(active) & __builtin_amdgcn_uicmp(w.cur, PT_REF_NONE, 33);
+                const unsigned long long leaf_mask = standing_mask & __builtin_amdgcn_sicmp((int)w.cur, 0, 40), node_mask = standing_mask & ~leaf_mask;
                 if((leaf_mask | node_mask) == 0ULL) {
                     break;
                 }
                 const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
                 w_steps++;
-                tr.step(w, rec, standing && !at_leaf, at_leaf && do_leaves, node_mask != 0ULL, do_leaves && leaf_mask != 0ULL, n_nodes, n_leaves);
+                tr.step(w, rec, node_mask, do_leaves ? leaf_mask : 0ULL, n_nodes, n_leaves);
             }
 #ifdef PT_PATH_TIMING
             t_burst += __builtin_amdgcn_s_memtime() - t_b0;
@@ -1174,9 +1234,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
 
     // Work counters: every wave owns one 64-byte slot (plain stores; atomics on a shared line from every wave serialise at the memory side)
     for(int off = 32; off > 0; off >>= 1) {
-        n_nodes += __shfl_down(n_nodes, off);
-        n_leaves += __shfl_down(n_leaves, off);
-        n_rays += __shfl_down(n_rays, off);
+        n_rays += __shfl_down(n_rays, off); // (n_nodes and n_leaves are counted for the whole wavefront: Tracer::step)
         n_shadow += __shfl_down(n_shadow, off);
         n_samples += __shfl_down(n_samples, off);
         n_vertices += __shfl_down(n_vertices, off);
@@ -1249,12 +1307,12 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
     tr.start(w, rec, root, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
     uint32_t n_nodes = 0, n_leaves = 0;
     for(;;) {
-        const bool standing = w.cur != PT_REF_NONE, at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
-        const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
+        const unsigned long long standing_mask = __builtin_amdgcn_uicmp(w.cur, PT_REF_NONE, 33);
+        const unsigned long long leaf_mask = standing_mask & __builtin_amdgcn_sicmp((int)w.cur, 0, 40), node_mask = standing_mask & ~leaf_mask;
         if((leaf_mask | node_mask) == 0ULL) {
             break;
         }
-        tr.step(w, rec, standing && !at_leaf, at_leaf, node_mask != 0ULL, leaf_mask != 0ULL, n_nodes, n_leaves);
+        tr.step(w, rec, node_mask, leaf_mask, n_nodes, n_leaves);
     }
     out[gid] = make_uint2(__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref);
 }
@@ -1299,8 +1357,8 @@ __global__ __launch_bounds__(256) void pt_steptime_kernel(PtDevScene sc, const f
     uint32_t n_nodes = 0, n_leaves = 0, steps = 0;
     unsigned long long waiting = 0;
     for(;;) {
-        const bool standing = w.cur != PT_REF_NONE, at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
-        const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
+        const unsigned long long standing_mask = __builtin_amdgcn_uicmp(w.cur, PT_REF_NONE, 33);
+        const unsigned long long leaf_mask = standing_mask & __builtin_amdgcn_sicmp((int)w.cur, 0, 40), node_mask = standing_mask & ~leaf_mask;
         if((leaf_mask | node_mask) == 0ULL) {
             break;
         }
@@ -1311,8 +1369,8 @@ __global__ __launch_bounds__(256) void pt_steptime_kernel(PtDevScene sc, const f
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             waiting += t2 - t1;
         }
-        steps += standing ? 1u : 0u;
-        tr.step(w, rec, standing && !at_leaf, at_leaf, node_mask != 0ULL, leaf_mask != 0ULL, n_nodes, n_leaves);
+        steps += 1u;
+        tr.step(w, rec, node_mask, leaf_mask, n_nodes, n_leaves);
     }
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     out[ray] = make_uint4(steps, (uint32_t)waiting, (uint32_t)(t_end - t_begin), (uint32_t)(t_again - t_begin));
@@ -1369,6 +1427,7 @@ __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, Pt
     w.o = v3(0, 0, 0);
     w.d = v3(0, 0, 1);
     w.inv = v3(0, 0, 0);
+    w.pack();
     w.thr = 0.0f;
     w.dest = 0;
     w.best_t = 0.0f;
@@ -1413,21 +1472,18 @@ __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, Pt
         }
 #pragma unroll 1
         for(int burst = 0; burst < burst_steps; burst++) {
-            const bool standing = active && w.cur != PT_REF_NONE;
-            const bool at_leaf = standing && (w.cur & PT_REF_LEAF) != 0;
-            const unsigned long long leaf_mask = __ballot(at_leaf), node_mask = __ballot(standing && !at_leaf);
+            const unsigned long long standing_mask = __ballot(active) & __builtin_amdgcn_uicmp(w.cur, PT_REF_NONE, 33);
+            const unsigned long long leaf_mask = standing_mask & __builtin_amdgcn_sicmp((int)w.cur, 0, 40), node_mask = standing_mask & ~leaf_mask;
             if((leaf_mask | node_mask) == 0ULL) {
                 break;
             }
             const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
             w_steps++;
-            tr.step(w, rec, standing && !at_leaf, at_leaf && do_leaves, node_mask != 0ULL, do_leaves && leaf_mask != 0ULL, n_nodes, n_leaves);
+            tr.step(w, rec, node_mask, do_leaves ? leaf_mask : 0ULL, n_nodes, n_leaves);
         }
     }
     for(int off = 32; off > 0; off >>= 1) {
-        n_nodes += __shfl_down(n_nodes, off);
-        n_leaves += __shfl_down(n_leaves, off);
-        n_rays += __shfl_down(n_rays, off);
+        n_rays += __shfl_down(n_rays, off); // (n_nodes and n_leaves are counted for the whole wavefront: Tracer::step)
         checksum += __shfl_down(checksum, off);
     }
     if(lane == 0) {

@@ -149,7 +149,7 @@ struct pt_scene {
     std::vector<float> emissive_cdf;
 
     // device scene
-    DevBuf<F4> pairs, tris, tri_shade, spheres, materials, lights, emis;
+    DevBuf<F4> recs, pairs, tris, tri_shade, spheres, materials, lights, emis; // (pairs and tris only while the scene is being built: linked into recs)
     DevBuf<uint2> sph_meta;
     DevBuf<float> emis_cdf;
     PtDevScene dev{};
@@ -293,17 +293,18 @@ int setup_path(pt_scene *s) {
     int stack_lds = env_int("PT_STACK_LDS", 8);
     cfg.stack_lds = stack_lds == 8 ? 8 : 16;
     cfg.rows = std::min(std::max(env_int("PT_ROWS", 4), 1), PT_MAX_ROWS);
-    cfg.lds_bytes = pt_path_lds_bytes(cfg.stack_lds, cfg.rows, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.n_lds_tris + 1U + s->dev.n_spheres : 0U);
+    cfg.lds_bytes = pt_path_lds_bytes(cfg.stack_lds, cfg.rows, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.pair_base : 0U);
     const int per_cu = pt_path_blocks_per_cu(cfg.stack_lds, cfg.in_lds, cfg.lds_bytes);
     const int limit = env_int("PT_BLOCKS_PER_CU", 0);
     s->path_blocks_per_cu = (limit > 0 && limit < per_cu) ? limit : per_cu;
-    cfg.spill_depth = s->depth > static_cast<uint32_t>(cfg.stack_lds) ? s->depth - static_cast<uint32_t>(cfg.stack_lds) : 1U;
+    // a walk's stack holds at most one parked node per level of the tree and the sentinel at its bottom (pt_path.hip); what does not fit the LDS window spills
+    cfg.spill_depth = s->depth + 2U > static_cast<uint32_t>(cfg.stack_lds) ? s->depth + 2U - static_cast<uint32_t>(cfg.stack_lds) : 1U;
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 12), 1), 64);
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
     cfg.ready_shift = std::min(std::max(env_int("PT_READY_SHIFT", 1), 0), 31);
     cfg.prefetch = env_int("PT_PREFETCH", 0) != 0 ? 1 : 0;
     cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 12), 1), 64);
-    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", cfg.in_lds ? 8 : 4), 1), 64); // measured: 4 for trees in HBM, 8 for scenes in LDS
+    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 8), 1), 64); // lanes that wait for the rare step before it runs: 2 -> 374, 4 -> 396, 8 -> 414, 12 -> 415, 16 -> 414 Msamples/s
     if(env_int("PT_DEBUG", 0) != 0) {
         std::fprintf(stderr, "[pt] path kernel: %d CUs x %d workgroups, %d rows of slots per wavefront, stack_lds %d, scene %s, lds %zu B, spill depth %u\n", s->cu_count,
                      s->path_blocks_per_cu, cfg.rows, cfg.stack_lds, cfg.in_lds ? "in LDS" : "in HBM", cfg.lds_bytes, cfg.spill_depth);
@@ -337,7 +338,7 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     // the streams that happen to share a wavefront with them wait for the same passes.  Such a job is dealt stream by stream (pieces of 1:
     // slot q of wavefront w renders stream q * waves + w), which gives every wavefront a sample of the whole job: the 1/8 share of the
     // benchmark frame 273 -> 221 ms at 256 spp, the 1/4 share 317 -> 259 (profiles/r03_share_rehearsal.txt).
-    const bool single_round = static_cast<uint64_t>(waves) * slots_per_wave >= n;
+    const bool single_round = static_cast<uint64_t>(waves) * slots_per_wave >= n && slots_per_wave <= 128U; // (a full grid of 4 rows balances well in pieces of 8: 423 against 409 Msamples/s)
     uint32_t first_lanes = static_cast<uint32_t>(env_int("PT_FIRST_LANES", single_round ? 1 : 8)); // full frame: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440, 4 -> 431 Msamples/s
     if(first_lanes == 0 || first_lanes > 64 || (first_lanes & (first_lanes - 1U)) != 0) {
         first_lanes = single_round ? 1 : 8;
@@ -975,9 +976,33 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     PT_HIP(s->emis.upload(emis));
     PT_HIP(s->emis_cdf.upload(cdf));
 
+    // ---- link: leaf records and pair records become ONE array, and the tree's references indices into it (pt_types.h) --------------
+    // (the pair records start on an even record: two sibling nodes on slots 2k, 2k + 1 share one aligned 128-byte line only then)
+    const uint32_t sphere_base = d->n_triangles + 1U, leaf_count = sphere_base + d->n_spheres, pair_base = (leaf_count + 1U) & ~1U;
+    if(static_cast<uint64_t>(pair_base) + n_pairs > PT_REF_INDEX) {
+        return fail(PT_ERR_UNSUPPORTED, "too many records for 30-bit references");
+    }
+    PT_HIP(s->recs.ensure(4 * (static_cast<size_t>(pair_base) + n_pairs)));
+    PT_HIP(hipMemcpyAsync(s->recs.ptr, s->tris.ptr, 4 * static_cast<size_t>(leaf_count) * sizeof(F4), hipMemcpyDeviceToDevice, s->stream));
+    if(pair_base > leaf_count) {
+        PT_HIP(hipMemsetAsync(s->recs.ptr + 4 * static_cast<size_t>(leaf_count), 0, 4 * sizeof(F4), s->stream));
+    }
+    if(n_pairs > 0) {
+        PT_HIP(hipMemcpyAsync(s->recs.ptr + 4 * static_cast<size_t>(pair_base), s->pairs.ptr, 4 * static_cast<size_t>(n_pairs) * sizeof(F4), hipMemcpyDeviceToDevice, s->stream));
+        PT_HIP(pt_link_records(s->stream, reinterpret_cast<float4 *>(s->recs.ptr), pair_base, n_pairs, sphere_base));
+    }
+    PT_HIP(hipStreamSynchronize(s->stream));
+    s->tris.release();
+    s->pairs.release();
+    if(root_ref != PT_REF_NONE) {
+        root_ref += (root_ref & PT_REF_LEAF) == 0 ? pair_base : ((root_ref & PT_REF_SPHERE) != 0 ? sphere_base : 0U);
+    }
+
     PtDevScene &dev = s->dev;
-    dev.pairs = reinterpret_cast<const float4 *>(s->pairs.ptr);
-    dev.tris = reinterpret_cast<const float4 *>(s->tris.ptr);
+    dev.recs = reinterpret_cast<const float4 *>(s->recs.ptr);
+    dev.pairs = dev.recs + 4 * static_cast<size_t>(pair_base);
+    dev.tris = dev.recs;
+    dev.pair_base = pair_base;
     dev.tri_shade = reinterpret_cast<const float4 *>(s->tri_shade.ptr);
     dev.spheres = reinterpret_cast<const float4 *>(s->spheres.ptr);
     dev.sph_meta = s->sph_meta.ptr;
@@ -999,7 +1024,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     dev.n_object_samples = static_cast<uint32_t>(object_sample_count);
     // LDS staging: a scene whose whole tree and triangle records fit in 24 KiB lives in LDS entirely (the path kernel's IN_LDS
     // variant); an LDS copy of only the top of a larger tree was measured in round 1 and does not pay.
-    const size_t small_bytes = static_cast<size_t>(n_pairs) * 64 + (static_cast<size_t>(d->n_triangles) + 1 + d->n_spheres) * 64;
+    const size_t small_bytes = (static_cast<size_t>(n_pairs) + pair_base) * 64;
     if(small_bytes <= 24 * 1024 && env_int("PT_LDS_SMALL", 1) != 0) {
         dev.n_lds_pairs = n_pairs;
         dev.n_lds_tris = d->n_triangles;
@@ -1079,9 +1104,10 @@ int pt_scene_bvh_dump(const pt_scene *scene, int32_t *out_obj, float *out_box, u
     }
     else {
         // rebuild the pre-order listing from the pair records in HBM
-        std::vector<F4> pairs(scene->pairs.count);
+        const uint32_t pair_base = scene->dev.pair_base, sphere_base = scene->dev.n_tris + 1U;
+        std::vector<F4> pairs(4 * static_cast<size_t>(scene->dev.n_pairs));
         if(hipSetDevice(scene->device) != hipSuccess ||
-           hipMemcpy(pairs.data(), scene->pairs.ptr, pairs.size() * sizeof(F4), hipMemcpyDeviceToHost) != hipSuccess) {
+           hipMemcpy(pairs.data(), scene->dev.pairs, pairs.size() * sizeof(F4), hipMemcpyDeviceToHost) != hipSuccess) {
             return fail(PT_ERR_HIP, "downloading the pair records failed");
         }
         struct Item {
@@ -1101,12 +1127,12 @@ int pt_scene_bvh_dump(const pt_scene *scene, int32_t *out_obj, float *out_box, u
             stack.pop_back();
             box.push_back(it.box);
             if((it.ref & PT_REF_LEAF) != 0) {
-                const uint32_t idx = it.ref & PT_REF_INDEX;
-                obj.push_back(static_cast<int32_t>((it.ref & PT_REF_SPHERE) != 0 ? scene->sph_obj[idx] : scene->tri_obj[idx]));
+                const uint32_t idx = it.ref & PT_REF_INDEX; // (record indices: pt_types.h)
+                obj.push_back(static_cast<int32_t>((it.ref & PT_REF_SPHERE) != 0 ? scene->sph_obj[idx - sphere_base] : scene->tri_obj[idx]));
             }
             else {
                 obj.push_back(-1);
-                const float *q = &pairs[4 * static_cast<size_t>(it.ref)].x;
+                const float *q = &pairs[4 * static_cast<size_t>(it.ref - pair_base)].x;
                 Item l, r;
                 std::memcpy(&l.box, q, 24);
                 std::memcpy(&r.box, q + 6, 24);
@@ -1162,14 +1188,15 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
             const float t = from_bits(hits[i].x);
             const uint32_t ref = hits[i].y;
             out_t[i] = t;
-            out_obj[i] = (t < 0.0F || ref == PT_REF_NONE) ? -1 : static_cast<int32_t>((ref & PT_REF_SPHERE) ? s->sph_obj[ref & PT_REF_INDEX] : s->tri_obj[ref & PT_REF_INDEX]);
+            out_obj[i] = (t < 0.0F || ref == PT_REF_NONE) ? -1 : static_cast<int32_t>((ref & PT_REF_SPHERE) ? s->sph_obj[(ref & PT_REF_INDEX) - (s->dev.n_tris + 1U)] : s->tri_obj[ref & PT_REF_INDEX]);
         }
         return PT_OK;
     }
 }
 
 // Diagnostic, not part of include/pt_hip.h: walks n rays, `lanes_per_wave` of them per wavefront, with every traversal step stamped.
-// out[4 * i ..] = steps, cycles spent waiting for records (flags bit 1: stamped run), cycles of the whole walk, -; flags bit 0: prefetch (tools/step_timing.py).
+// out[4 * i ..] = steps, cycles spent waiting for records (flags bit 1: stamped run), cycles of the whole walk, -; flags bit 0: prefetch;
+// behind the n results, 8 segment totals of 8 bytes per ray from a -DPT_STEP_STAMPS build (zeros otherwise): out holds 20 * n words (tools/step_timing.py).
 extern "C" int pt_debug_step_timing(pt_scene *s, const float *rays, size_t n, int lanes_per_wave, int flags, uint32_t *out) {
     if(s == nullptr || rays == nullptr || out == nullptr || n == 0 || n > 0x3fffffULL || lanes_per_wave < 1 || lanes_per_wave > 64) {
         return fail(PT_ERR_INVALID, "bad argument");
@@ -1189,13 +1216,14 @@ extern "C" int pt_debug_step_timing(pt_scene *s, const float *rays, size_t n, in
     DevBuf<uint4> d_out;
     DevBuf<uint2> d_spill;
     PT_HIP(d_rays.ensure(6 * n));
-    PT_HIP(d_out.ensure(n));
+    PT_HIP(d_out.ensure(5 * n));
+    PT_HIP(hipMemsetAsync(d_out.ptr, 0, 5 * n * sizeof(uint4), s->stream));
     PT_HIP(d_spill.ensure(threads * s->path_cfg.spill_depth));
     hipStream_t st = s->stream;
     PT_HIP(hipMemcpyAsync(d_rays.ptr, rays, 6 * n * sizeof(float), hipMemcpyHostToDevice, st));
     pt_launch_steptime(st, s->dev, d_rays.ptr, static_cast<uint32_t>(n), static_cast<uint32_t>(lanes_per_wave), d_out.ptr, d_spill.ptr, s->path_cfg.spill_depth, flags);
     PT_HIP(hipGetLastError());
-    PT_HIP(hipMemcpyAsync(out, d_out.ptr, n * sizeof(uint4), hipMemcpyDeviceToHost, st));
+    PT_HIP(hipMemcpyAsync(out, d_out.ptr, 5 * n * sizeof(uint4), hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
     return PT_OK;
 }
@@ -1231,65 +1259,6 @@ extern "C" int pt_debug_replay_rays(pt_scene *s, int waves_per_simd, int parts, 
     return PT_OK;
 }
 
-// Diagnostic, not part of include/pt_hip.h: rewrites the pair records of a scene in another ORDER (the tree is the same: only the
-// positions of the records and the child references in them change), to measure what the memory layout is worth.  The records come
-// out in treelets of `levels` levels (breadth-first inside a treelet, treelets depth-first); levels = 1 is a depth-first pre-order.
-extern "C" int pt_debug_relayout_pairs(pt_scene *s, int levels) {
-    if(s == nullptr || levels < 1 || s->pairs.ptr == nullptr || s->dev.n_pairs == 0 || (s->dev.root_ref & PT_REF_LEAF) != 0) {
-        return fail(PT_ERR_INVALID, "nothing to lay out");
-    }
-    std::lock_guard<std::mutex> lock(s->render_mutex);
-    PT_HIP(hipSetDevice(s->device));
-    const size_t n = s->dev.n_pairs;
-    std::vector<F4> old_rec(4 * n), new_rec(4 * n);
-    PT_HIP(hipMemcpy(old_rec.data(), s->pairs.ptr, old_rec.size() * sizeof(F4), hipMemcpyDeviceToHost));
-    auto child = [&](uint32_t node, int k) { return bits(k == 0 ? old_rec[4 * static_cast<size_t>(node) + 3].x : old_rec[4 * static_cast<size_t>(node) + 3].y); };
-    std::vector<uint32_t> pos(n, PT_REF_NONE), order;
-    order.reserve(n);
-    std::vector<uint32_t> roots{s->dev.root_ref & PT_REF_INDEX}, level, next;
-    while(!roots.empty()) {
-        const uint32_t r = roots.back();
-        roots.pop_back();
-        level.assign(1, r);
-        std::vector<uint32_t> frontier;
-        for(int d = 0; d < levels && !level.empty(); d++) {
-            next.clear();
-            for(uint32_t node : level) {
-                pos[node] = static_cast<uint32_t>(order.size());
-                order.push_back(node);
-                for(int k = 0; k < 2; k++) {
-                    const uint32_t c = child(node, k);
-                    if(c != PT_REF_NONE && (c & PT_REF_LEAF) == 0) {
-                        next.push_back(c);
-                    }
-                }
-            }
-            level.swap(next);
-        }
-        for(size_t i = level.size(); i-- > 0;) { // the leftmost treelet below comes next
-            roots.push_back(level[i]);
-        }
-    }
-    if(order.size() > n) {
-        return fail(PT_ERR_INVALID, "pair records reached twice");
-    }
-    // (the breadth-first array has unused slots where a sibling pair was aligned to a line: the new order is dense, the tail stays empty)
-    for(size_t i = 0; i < order.size(); i++) {
-        const uint32_t src = order[i];
-        for(int q = 0; q < 4; q++) {
-            new_rec[4 * i + q] = old_rec[4 * static_cast<size_t>(src) + q];
-        }
-        for(int k = 0; k < 2; k++) {
-            const uint32_t c = child(src, k);
-            if(c != PT_REF_NONE && (c & PT_REF_LEAF) == 0) {
-                (k == 0 ? new_rec[4 * i + 3].x : new_rec[4 * i + 3].y) = from_bits(pos[c]);
-            }
-        }
-    }
-    PT_HIP(hipMemcpy(s->pairs.ptr, new_rec.data(), new_rec.size() * sizeof(F4), hipMemcpyHostToDevice));
-    s->dev.root_ref = pos[s->dev.root_ref & PT_REF_INDEX];
-    return PT_OK;
-}
 
 int pt_render_streams(pt_scene *s, const pt_camera_params *camera, const pt_options *options, const pt_stream *streams, size_t n, float *out_image,
                       uint64_t *out_states, pt_stats *stats) {

@@ -46,6 +46,10 @@ struct PtBuildOutput {
 hipError_t pt_build_scene_device(hipStream_t stream, const PtBuildInput &in, PtBuildOutput &out, const char **error_text);
 
 
+// Turns the local indices of the tree's references into record indices (pt_types.h): recs = [leaf records | n_pairs pair records from
+// record pair_base on]; a reference to pair slot p becomes pair_base + p, one to sphere i becomes sphere_base + i, triangles keep theirs.
+hipError_t pt_link_records(hipStream_t stream, float4 *recs, uint32_t pair_base, uint32_t n_pairs, uint32_t sphere_base);
+
 // Positions of the objects whose bit is set in `mask_bits` (host array, one bit per object) within the depth-first leaf order
 // `dfs` (device).  On return `ordered` lists those objects in depth-first order.
 hipError_t pt_build_order_subset(hipStream_t stream, const uint32_t *dfs, uint32_t n_objects, const std::vector<uint32_t> &mask_bits, uint32_t n_selected,

@@ -869,6 +869,38 @@ hipError_t pt_build_scene_device(hipStream_t stream, const PtBuildInput &in, PtB
     return hipSuccess;
 }
 
+__global__ void k_link_records(float4 *__restrict__ recs, uint32_t pair_base, uint32_t n_pairs, uint32_t sphere_base) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if(p >= n_pairs) {
+        return;
+    }
+    float4 *q3 = recs + 4 * (static_cast<size_t>(pair_base) + p) + 3;
+    float4 v = *q3;
+    uint32_t ref[2] = {__float_as_uint(v.x), __float_as_uint(v.y)};
+    for(int c = 0; c < 2; c++) {
+        if(ref[c] == PT_REF_NONE) {
+            continue; // (an unused slot of the sibling alignment)
+        }
+        if((ref[c] & PT_REF_LEAF) == 0) {
+            ref[c] += pair_base;
+        }
+        else if((ref[c] & PT_REF_SPHERE) != 0) {
+            ref[c] += sphere_base;
+        }
+    }
+    v.x = __uint_as_float(ref[0]);
+    v.y = __uint_as_float(ref[1]);
+    *q3 = v;
+}
+
+hipError_t pt_link_records(hipStream_t stream, float4 *recs, uint32_t pair_base, uint32_t n_pairs, uint32_t sphere_base) {
+    if(n_pairs == 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_link_records, grid_for(n_pairs), dim3(256), 0, stream, recs, pair_base, n_pairs, sphere_base);
+    return hipGetLastError();
+}
+
 hipError_t pt_build_order_subset(hipStream_t stream, const uint32_t *dfs, uint32_t n_objects, const std::vector<uint32_t> &mask_bits, uint32_t n_selected,
                                  std::vector<uint32_t> &ordered) {
     ordered.clear();

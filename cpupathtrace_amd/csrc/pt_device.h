@@ -484,8 +484,9 @@ PT_D V3 tri_shade_normal(F4Ptr rec, V3 pos, uint32_t &material) {
 }
 
 PT_D V3 object_normal(const PtDevScene &sc, uint32_t ref, V3 pos, uint32_t &material) {
-    uint32_t idx = ref & PT_REF_INDEX;
+    uint32_t idx = ref & PT_REF_INDEX; // (a hit carries the index of the object's record: pt_types.h)
     if(ref & PT_REF_SPHERE) {
+        idx -= sc.n_tris + 1u;
         float4 s = sc.spheres[idx];
         material = sc.sph_meta[idx].x;
         return normalize(pos - v3(s.x, s.y, s.z)); // object.cpp:86-88

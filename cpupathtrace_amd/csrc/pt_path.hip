@@ -37,6 +37,8 @@
 // gfx950 specifics: 64-wide ballots/popcounts for compaction, typed LDS/global address spaces (a pointer that may be either makes
 // hipcc emit flat_load), per-lane traversal stack in LDS as [entry][lane] (conflict-free ds_read/write_b64) with an HBM spill area
 // for unusually deep walks, LDS atomics for the per-slot completion words, no MFMA (there is no dense contraction on this path).
+#include <type_traits>
+
 #include "pt_device.h"
 #include "pt_kernels.h"
 #include "pt_shading.h"
@@ -93,10 +95,25 @@ struct RootBox {
 };
 
 // One walk (one ray) in a lane.
+//
+// `cur` is where the walk stands: the reference of an inner node (bits 31, 30 = 00) or of a leaf (bit 31 set, pt_types.h), PT_REF_NONE when
+// the walk is over, or PT_REF_POPPING when it has to return to a parked node but the entry on top of its stack has already been
+// discarded (see Tracer::node_step).  The stack of parked nodes has a SENTINEL as entry 0 -- (PT_REF_NONE, -1) -- so "the stack is
+// empty" needs no test anywhere: popping the sentinel ends the walk, and its distance passes every pruning test.
+#define PT_REF_POPPING 0xfffffffeu
 struct Walk {
     V3 o, d, inv;
-#ifdef PT_PACKED_SLAB
     f2v o_xy, o_zx, o_yz, i_xy, i_zx, i_yz; // origin and inverse direction again, as the register pairs of the packed slab arithmetic
+    float thr;       // shadow threshold |to_light| - epsilon (worker.cpp:86)
+    uint32_t dest;   // destination word of the ray
+    float best_t;
+    uint32_t best_ref;
+    float t_max;     // pruning distance: the smallest hit distance so far (scene.cpp:124,137)
+    float t_lim;     // the largest float below t_max: x < t_max  <=>  x <= t_lim, which lets min() fold the pruning test into the box test
+    uint32_t cur;
+    uint32_t sp;     // entries on the stack, the sentinel included
+    bool occluded;   // shadow ray: a leaf closer than the light was found
+
     PT_D void pack() {
         o_xy = (f2v){o.x, o.y};
         o_zx = (f2v){o.z, o.x};
@@ -105,53 +122,75 @@ struct Walk {
         i_zx = (f2v){inv.z, inv.x};
         i_yz = (f2v){inv.y, inv.z};
     }
-#else
-    PT_D void pack() {}
-#endif
-    float thr;       // shadow threshold |to_light| - epsilon (worker.cpp:86)
-    uint32_t dest;   // destination word of the ray
-    float best_t;
-    uint32_t best_ref;
-    float t_max;
-    uint32_t cur;    // node or leaf the walk stands on; PT_REF_NONE = finished
-    uint32_t sp;
-    bool occluded;   // shadow ray: a leaf closer than the light was found
+    // t_max is never negative (hit distances are >= 0; it may be -0): below zero there is nothing, and every entry distance is >= 0
+    PT_D void set_t_max(float t) {
+        t_max = t;
+        t_lim = t > 0.0f ? __uint_as_float(__float_as_uint(t) - 1u) : -1.0f;
+    }
 };
 
 // The traversal machinery of one lane: record arrays (LDS or HBM), the stack window in LDS and its HBM spill area.
 //
-// How a step is written matters as much as what it computes: a wavefront's step is a chain load -> slab tests -> decision -> address ->
-// load, and with few wavefronts per SIMD (a strong-scaling share, the tail of any job) its length IS the frame time, because a
-// stream's samples are sequential.  So the step below is straight-line code under WAVE-UNIFORM branches ("does any lane stand on an
-// inner node / a leaf / need to pop": one scalar branch each), with per-lane differences expressed as selects and one exec-masked
-// LDS store; records of both kinds have one stride (64 bytes), so the next record's address is one select and one shift-add.  The
-// version it replaces nested five divergent ifs per step and spent 109 scalar instructions per step on exec-mask bookkeeping
-// (profiles/r02_pmc_replay_kernel.txt).
+// What a step costs on this chip (tools/issue_probe.hip, profiles/r03_issue_probe.txt): a wavefront that is alone on its SIMD issues one
+// instruction per 4.5 cycles whatever the instruction; a taken branch costs 22 cycles, a not-taken one 13, a wave-uniform branch on a
+// ballot (v_cmp into an SGPR pair, s_cmp, s_cbranch) 35-52, a lane mask that goes through the scalar unit on its way to a v_cndmask
+// 16 more than one that stays in vcc, an LDS round trip 55, an L1 hit 112.  A stream's samples are sequential, so at the end of every
+// launch -- and for the whole of a strong-scaling share -- the frame time is the length of a few such lonely chains.  Hence:
+//   * node_step is STRAIGHT-LINE code for all 64 lanes, no branch and no exec mask but the one around the record loads.  Conditions
+//     never meet in scalar registers: a child that is not entered gets the entry distance +inf, and min / max / compare-with-inf on
+//     the two distances yield near child, far child, "both" and "none" (each v_cmp feeds the v_cndmask or the add-with-carry behind
+//     it through vcc).  The far child is written ABOVE the top of the stack by every lane (it only becomes an entry where the stack
+//     pointer moves) and the top entry is read by every lane ahead of the arithmetic, so the first pop of the recursion's return
+//     (scene.cpp:137) costs no trip to LDS;
+//   * everything rare -- leaves, a popped entry that fails the distance test, a stack deeper than its LDS window -- is left to
+//     slow_step, which the traversal loop enters through ONE wave-uniform branch per step.
+// Diagnostic build (-DPT_STEP_STAMPS, tools/step_timing.py): s_memtime stamps inside the step; segment k collects the cycles from the
+// previous stamp to stamp k, each inflated by the round trip of the previous stamp itself (segment 7 = two stamps back to back: that price)
+#ifdef PT_STEP_STAMPS
+#define PT_STAMP(k)                                                      \
+    do {                                                                 \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+        stamp_acc[k] += now_ - stamp_last;                               \
+        stamp_last = now_;                                               \
+    } while(0)
+#else
+#define PT_STAMP(k) do { } while(0)
+#endif
+
 template<int STACK_LDS, bool IN_LDS>
 struct Tracer {
     static_assert((STACK_LDS & (STACK_LDS - 1)) == 0, "the stack window is indexed with a mask");
+#ifdef PT_STEP_STAMPS
+    mutable unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
+#endif
     typedef typename RecPtr<IN_LDS>::type rec_ptr;
-    rec_ptr pairs, tris;  // 64-byte records both (pt_types.h)
-    uint32_t sphere_base; // record of sphere 0 in `tris`
-    bool prefetch;        // request the line of a node's inner children as soon as the node's record is there (see step)
-    lds_u2_ptr stack_l; // this thread's column: entry e at stack_l[e * 256]
-    glb_u2_ptr my_spill;
+    rec_ptr recs;         // the 64-byte records the tree's references index: leaves, then pairs (pt_types.h)
+    lds_u2_ptr stack_l;   // this thread's column: entry e at stack_l[(e mod STACK_LDS) * 256]
+    glb_u2_ptr my_spill;  // entries that have left the window: entry e at my_spill[e]
 
     // The 64-byte record a walk stands on, requested as soon as the walk knows where it goes next: a node's pair of child boxes, a
-    // triangle, or a sphere's (origin, radius) -- the spheres' records stand behind the triangles', so there is no special case.
+    // triangle, or a sphere's (origin, radius).  A reference's low 30 bits ARE the record's index: one mask, one shift-add.
     struct Rec {
         f4v r0, r1, r2, r3;
-        uint32_t warm; // a word of the line requested ahead (never used: it keeps the request alive until the next step's wait)
     };
     PT_D void fetch(uint32_t cur, Rec &R) const {
-        const bool leaf = (cur & PT_REF_LEAF) != 0;
-        const uint32_t idx = (cur & PT_REF_INDEX) + ((cur & PT_REF_SPHERE) ? sphere_base : 0u); // (bit 30 is never set in an inner reference)
-        rec_ptr p = (leaf ? tris : pairs) + 4 * (size_t)idx;
+        rec_ptr p = recs + 4 * (size_t)(cur & PT_REF_INDEX);
         R.r0 = p[0];
         R.r1 = p[1];
         R.r2 = p[2];
         R.r3 = p[3];
     }
+    // Registers that a load fills and nobody reads (the last two words of a record) become the compiler's scratch registers, and their
+    // first use then has to wait for the load: a full memory latency at the end of every step.  Every consumer of a record calls this.
+    static PT_D void whole(const Rec &R) {
+        asm volatile("" ::"v"(R.r0), "v"(R.r1), "v"(R.r2), "v"(R.r3));
+    }
+
+    // Where a walk stands, classified with one comparison each: a reference below 2^30 = an inner node (node_step moves it); at or above,
+    // except PT_REF_NONE = it waits for slow_step (a leaf, or a walk that has to go on popping).
+    static PT_D unsigned long long node_lanes(uint32_t cur) { return __builtin_amdgcn_uicmp(cur, 0x40000000u, 36); }       // cur < 2^30
+    static PT_D unsigned long long slow_lanes(uint32_t cur) { return __builtin_amdgcn_uicmp(cur + 1u, 0x40000000u, 34); }  // 2^30 <= cur < NONE
 
     // Start a walk: Scene::getIntersection tests the root box first (scene.cpp:211-219).
     PT_D void start(Walk &w, Rec &R, const RootBox &root, float4 ro, float4 rd) const {
@@ -170,8 +209,10 @@ struct Tracer {
         // below.  A box around a flat, axis-aligned emitter is entered at that very distance (again up to rounding, of the slab test
         // this time), so pruning at the threshold skipped the emitter in cases where the reference tested it and found t < threshold.
         // The walk still ends at the first hit below the threshold (the closest hit can only be nearer).
-        w.t_max = FLT_MAX;
-        w.sp = 0;
+        w.set_t_max(FLT_MAX);
+        const u2v sentinel = {PT_REF_NONE, __float_as_uint(-1.0f)};
+        stack_l[0] = sentinel;
+        w.sp = 1;
         w.occluded = false;
         w.cur = PT_REF_NONE;
         if(root.ref != PT_REF_NONE) {
@@ -183,118 +224,92 @@ struct Tracer {
         }
     }
 
-    // One step of the wavefront's walks.  `node_mask`: the lanes that stand on an inner node whose record is in R; `leaf_mask`: the lanes that
-    // stand on a leaf whose record is in R and whose leaf code runs in this step.  Lanes in neither keep their walk and their record.
-    // Every lane that moved requests the record of where it stands next.  n_nodes / n_leaves count visits for the whole wavefront
-    // (the same value in every lane).
-    //
-    // The decisions are taken on WAVE MASKS in scalar registers (v_cmp into an SGPR pair, s_and / s_or on it, the mask as the condition of
-    // a v_cndmask): no lane-boolean is ever materialised in a vector register and nothing is exec-masked on the common path.
-    static PT_D unsigned long long f_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5); }  // ordered <=
-    static PT_D unsigned long long f_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }  // ordered <
-    static PT_D unsigned long long u_ge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35); }
-    static PT_D unsigned long long u_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
-    static PT_D bool lane_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
-
-    PT_D void step(Walk &w, Rec &R, unsigned long long node_mask, unsigned long long leaf_mask, uint32_t &n_nodes, uint32_t &n_leaves) const {
-        unsigned long long pop_mask = 0ULL; // lanes that go on popping in the loop at the end
-        uint32_t cur = w.cur;
-        if(node_mask != 0ULL) {
-            // AABB::getIntersection of both children (bounding_box.cpp:38-73): a box is hit iff t_max >= 0 and t_min <= t_max -- the same
-            // as max(t_min, 0) <= t_max -- and its entry distance is max(t_min, 0) (0 = origin inside, :68-70).
-            // impl::getChildIntersection (scene.cpp:113-146): a child is entered iff it is hit and its entry distance is below the pruning
-            // distance; with both entered the nearer one comes first -- on equal distances the RIGHT one (scene.cpp:120-121) -- and the
-            // other is parked with its entry distance.  (Lanes that do not stand on a node compute on whatever their registers hold and
-            // discard it.)
-            const f4v q0 = R.r0, q1 = R.r1, q2 = R.r2, q3 = R.r3;
-            if constexpr(!IN_LDS) {
-                asm volatile("" ::"v"(R.warm));
-                if(prefetch) {
-                    // The step is a chain record -> slab tests -> decision -> next record, and with few wavefronts per SIMD nothing hides the
-                    // second fetch behind the arithmetic.  The records of a node's two inner children share one aligned 128-byte line
-                    // (breadth-first slots, siblings on even / odd slots): one word of it is requested NOW, so that the record the decision
-                    // picks comes out of the cache.  (A node with two leaves asks for the tree's root: a cache hit.)
-                    const uint32_t l = __float_as_uint(q3.x), r = __float_as_uint(q3.y);
-                    const uint32_t inner = (l & PT_REF_LEAF) ? r : l;
-                    const uint32_t line = (lane_of(node_mask) && !(inner & PT_REF_LEAF)) ? inner : 0u;
-                    R.warm = *reinterpret_cast<const uint32_t __attribute__((address_space(1))) *>((glb_f4_cptr)pairs + 4 * (size_t)line);
-                }
-            }
-            const uint32_t sp = w.sp;
-            const float t_max = w.t_max;
-            // the top entry of the lane's stack, read ahead of the arithmetic that decides whether it is needed (see below; a lane with an
-            // empty stack reads a slot nobody looks at)
-            const u2v top = stack_l[((sp - 1u) & (uint32_t)(STACK_LDS - 1)) * 256u];
-#ifdef PT_PACKED_SLAB
-            // the same twelve differences and products as below, two per instruction (v_pk_add_f32 with a negated operand is the IEEE
-            // subtraction, v_pk_mul_f32 the IEEE product: nothing is fused)
-            const f2v a0 = ((f2v){q0.x, q0.y} - w.o_xy) * w.i_xy; // L.lo.x, L.lo.y
-            const f2v a1 = ((f2v){q0.z, q0.w} - w.o_zx) * w.i_zx; // L.lo.z, L.hi.x
-            const f2v a2 = ((f2v){q1.x, q1.y} - w.o_yz) * w.i_yz; // L.hi.y, L.hi.z
-            const f2v a3 = ((f2v){q1.z, q1.w} - w.o_xy) * w.i_xy; // R.lo.x, R.lo.y
-            const f2v a4 = ((f2v){q2.x, q2.y} - w.o_zx) * w.i_zx; // R.lo.z, R.hi.x
-            const f2v a5 = ((f2v){q2.z, q2.w} - w.o_yz) * w.i_yz; // R.hi.y, R.hi.z
-            const float l1 = a0.x, l2 = a1.y, l3 = a0.y, l4 = a2.x, l5 = a1.x, l6 = a2.y;
-            const float r1t = a3.x, r2t = a4.y, r3t = a3.y, r4t = a5.x, r5t = a4.x, r6t = a5.y;
-#else
-            const V3 o = w.o, inv = w.inv;
-            const float l1 = (q0.x - o.x) * inv.x, l2 = (q0.w - o.x) * inv.x;
-            const float l3 = (q0.y - o.y) * inv.y, l4 = (q1.x - o.y) * inv.y;
-            const float l5 = (q0.z - o.z) * inv.z, l6 = (q1.y - o.z) * inv.z;
-            const float r1t = (q1.z - o.x) * inv.x, r2t = (q2.y - o.x) * inv.x;
-            const float r3t = (q1.w - o.y) * inv.y, r4t = (q2.z - o.y) * inv.y;
-            const float r5t = (q2.x - o.z) * inv.z, r6t = (q2.w - o.z) * inv.z;
+    // One step of every walk that stands on an inner node (`node_mask`); the record of where a walk stands next is requested.
+    // AABB::getIntersection of both children (bounding_box.cpp:38-73): a box is hit iff t_max >= 0 and t_min <= t_max -- the
+    // same as max(t_min, 0) <= t_max -- and its entry distance is max(t_min, 0) (0 = origin inside, :68-70).
+    // impl::getChildIntersection (scene.cpp:113-146): a child is entered iff it is hit and its entry distance is below the pruning
+    // distance (entry < t_max <=> entry <= t_lim, so both tests are ONE comparison with min(box exit, t_lim)); with both entered the
+    // nearer one comes first -- on equal distances the RIGHT one (scene.cpp:120-121): "left first" is a strict less-than -- and the other
+    // is parked with its entry distance; with none entered the walk returns to the node on top of its stack if that one's entry
+    // distance is still below the pruning distance (scene.cpp:137), and goes on popping in slow_step otherwise.
+    // The stack: the top STACK_LDS entries of a lane live in LDS (slot = index mod STACK_LDS), older ones in the lane's HBM spill area.
+    // `deep_mask`: the lanes whose stack has left the window -- for them a push first moves the entry it overwrites to the spill area and
+    // a pop brings the entry that left the window last back into the slot that has become free; if there is no such lane (one scalar
+    // branch) the far child is simply written ABOVE the top of the stack by every lane: it only becomes an entry where the pointer moves.
+    PT_D void node_step(Walk &w, Rec &R, unsigned long long node_mask, unsigned long long deep_mask) const {
+        if(!__builtin_amdgcn_inverse_ballot_w64(node_mask)) {
+            return; // (the one exec mask of the step; the caller knows the mask is not empty)
+        }
+#ifdef PT_STEP_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-            const float l_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(l1, l2), __builtin_fminf(l3, l4)), __builtin_fminf(l5, l6));
-            const float l_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(l1, l2), __builtin_fmaxf(l3, l4)), __builtin_fmaxf(l5, l6));
-            const float r_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r1t, r2t), __builtin_fminf(r3t, r4t)), __builtin_fminf(r5t, r6t));
-            const float r_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r1t, r2t), __builtin_fmaxf(r3t, r4t)), __builtin_fmaxf(r5t, r6t));
-            const float left_t = __builtin_fmaxf(l_min, 0.0f), right_t = __builtin_fmaxf(r_min, 0.0f);
-            const unsigned long long go_left = f_le(left_t, l_max) & f_lt(left_t, t_max);
-            const unsigned long long go_right = f_le(right_t, r_max) & f_lt(right_t, t_max);
-            const unsigned long long take_left_m = go_left & (~go_right | f_lt(left_t, right_t));
-            const unsigned long long both_m = go_left & go_right & node_mask;
-            const unsigned long long entered_m = go_left | go_right;
-            const bool take_left = lane_of(take_left_m);
-            const uint32_t left_ref = __float_as_uint(q3.x), right_ref = __float_as_uint(q3.y);
-            const uint32_t near_ref = take_left ? left_ref : right_ref;
-            const u2v far = {take_left ? right_ref : left_ref, __float_as_uint(take_left ? right_t : left_t)};
-            // park the far child: the top STACK_LDS entries of a lane's stack live in LDS (slot = index mod STACK_LDS), older ones in the
-            // lane's HBM spill area
-            const uint32_t slot = (sp & (uint32_t)(STACK_LDS - 1)) * 256u;
-            n_nodes += (uint32_t)__popcll(node_mask);
-            if(u_ge(sp, (uint32_t)STACK_LDS) == 0ULL) {
-                // No lane's stack reaches beyond its window (the common case, one scalar branch).  The far child is written ABOVE the top
-                // of the stack by every lane -- it only becomes an entry where the stack pointer moves -- and the top entry is read by
-                // every lane, so that a lane that entered no child continues with it at once (the first pop of the recursion's return,
-                // scene.cpp:137) without a second trip to LDS; only a popped entry that fails the distance test sends the lane into the
-                // loop below.
-                stack_l[slot] = far;
-                const unsigned long long pop1_m = node_mask & ~entered_m & u_ne(sp, 0u);
-                const unsigned long long popped_m = pop1_m & f_lt(__uint_as_float(top.y), t_max);
-                const uint32_t next = lane_of(entered_m) ? near_ref : (lane_of(popped_m) ? top.x : PT_REF_NONE);
-                cur = lane_of(node_mask) ? next : cur;
-                w.sp = sp + (lane_of(both_m) ? 1u : 0u) - (lane_of(pop1_m) ? 1u : 0u);
-                pop_mask = pop1_m & ~popped_m;
+        PT_STAMP(2); // waiting for the record
+        whole(R);
+        const f4v q0 = R.r0, q1 = R.r1, q2 = R.r2;
+        const uint32_t sp = w.sp;
+        const u2v top = stack_l[((sp - 1u) & (uint32_t)(STACK_LDS - 1)) * 256u]; // read ahead of the arithmetic that decides whether it is needed
+        // twelve differences and products, two per instruction (v_pk_add_f32 with a negated operand is the IEEE subtraction,
+        // v_pk_mul_f32 the IEEE product: nothing is fused, every result is the reference's)
+        const f2v a0 = ((f2v){q0.x, q0.y} - w.o_xy) * w.i_xy; // L.lo.x, L.lo.y
+        const f2v a1 = ((f2v){q0.z, q0.w} - w.o_zx) * w.i_zx; // L.lo.z, L.hi.x
+        const f2v a2 = ((f2v){q1.x, q1.y} - w.o_yz) * w.i_yz; // L.hi.y, L.hi.z
+        const f2v a3 = ((f2v){q1.z, q1.w} - w.o_xy) * w.i_xy; // R.lo.x, R.lo.y
+        const f2v a4 = ((f2v){q2.x, q2.y} - w.o_zx) * w.i_zx; // R.lo.z, R.hi.x
+        const f2v a5 = ((f2v){q2.z, q2.w} - w.o_yz) * w.i_yz; // R.hi.y, R.hi.z
+        const float l1 = a0.x, l2 = a1.y, l3 = a0.y, l4 = a2.x, l5 = a1.x, l6 = a2.y;
+        const float r1 = a3.x, r2 = a4.y, r3 = a3.y, r4 = a5.x, r5 = a4.x, r6 = a5.y;
+        const float l_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(l1, l2), __builtin_fminf(l3, l4)), __builtin_fminf(l5, l6));
+        const float l_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(l1, l2), __builtin_fmaxf(l3, l4)), __builtin_fmaxf(l5, l6));
+        const float r_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(r1, r2), __builtin_fminf(r3, r4)), __builtin_fminf(r5, r6));
+        const float r_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(r1, r2), __builtin_fmaxf(r3, r4)), __builtin_fmaxf(r5, r6));
+        const float left_t = __builtin_fmaxf(l_min, 0.0f), right_t = __builtin_fmaxf(r_min, 0.0f);
+        const float inf = __builtin_inff();
+        const float t_lim = w.t_lim;
+        const float tl = left_t <= __builtin_fminf(l_max, t_lim) ? left_t : inf;   // entry distance of a child that is entered, else +inf
+        const float tr = right_t <= __builtin_fminf(r_max, t_lim) ? right_t : inf;
+        const bool left_first = tl < tr;
+        const uint32_t left_ref = __float_as_uint(R.r3.x), right_ref = __float_as_uint(R.r3.y);
+        const uint32_t near_ref = left_first ? left_ref : right_ref;
+        const float near_t = __builtin_fminf(tl, tr), far_t = __builtin_fmaxf(tl, tr);
+        const u2v far = {left_first ? right_ref : left_ref, __float_as_uint(far_t)};
+        const bool both = far_t < inf, entered = near_t < inf;
+        const uint32_t slot = (sp & (uint32_t)(STACK_LDS - 1)) * 256u;
+        if(deep_mask == 0ULL) {
+            stack_l[slot] = far;
+        }
+        else if(both) {
+            if(sp >= (uint32_t)STACK_LDS) {
+                my_spill[sp - STACK_LDS] = stack_l[slot];
             }
-            else {
-                // pushing onto a full window first moves the entry about to be overwritten to the spill area
-                const bool both = lane_of(both_m);
-                if(both & (sp >= (uint32_t)STACK_LDS)) {
-                    my_spill[sp - STACK_LDS] = stack_l[slot];
-                }
-                if(both) {
-                    stack_l[slot] = far;
-                    w.sp = sp + 1u;
-                }
-                cur = lane_of(node_mask) ? (lane_of(entered_m) ? near_ref : PT_REF_NONE) : cur;
-                pop_mask = node_mask & ~entered_m;
+            stack_l[slot] = far;
+        }
+        const uint32_t popped = __uint_as_float(top.y) <= t_lim ? top.x : PT_REF_POPPING;
+        const uint32_t next = entered ? near_ref : popped;
+        w.sp = entered ? sp + (both ? 1u : 0u) : sp - 1u;
+        w.cur = next;
+        asm volatile("" ::"v"(w.sp), "v"(w.cur)); // (the walk's new state is complete before the record is requested: nothing is left to do behind the loads)
+        PT_STAMP(3); // slab tests, decision, stack
+        // the lanes that moved onto a record (not the ones whose walk ended or that go on popping: the two codes at the top)
+        if(next < PT_REF_POPPING) {
+            fetch(next, R);
+        }
+        if(deep_mask != 0ULL) {
+            if(!entered & (sp - 1u >= (uint32_t)STACK_LDS)) {
+                stack_l[((sp - 1u) & (uint32_t)(STACK_LDS - 1)) * 256u] = my_spill[sp - 1u - STACK_LDS]; // the window moves down
             }
         }
+        PT_STAMP(4); // address and request of the next record
+    }
+
+    // Everything that is not the common step: the leaves in `leaf_mask` (Object::getIntersection) and the walks that must (go on) pop(ping).
+    // n_leaves counts visits for the whole wavefront (the same value in every lane).
+    PT_D void slow_step(Walk &w, Rec &R, unsigned long long leaf_mask, uint32_t &n_leaves) const {
+        uint32_t cur = w.cur;
+        bool need_pop = cur == PT_REF_POPPING;
+        bool moved = false;
         if(leaf_mask != 0ULL) {
             n_leaves += (uint32_t)__popcll(leaf_mask);
-            bool leaf_pop = false;
-            if(lane_of(leaf_mask)) {
+            if(__builtin_amdgcn_inverse_ballot_w64(leaf_mask)) {
                 // a leaf reports Object::getIntersection unconditionally (scene.cpp:105-109); among the non-negative hits the smallest wins and a
                 // later-visited leaf wins ties (scene.cpp:141-146); a shadow walk ends at its first hit below the threshold (worker.cpp:86)
                 const float4 q0 = to_f4(R.r0), q1 = to_f4(R.r1), q2 = to_f4(R.r2);
@@ -306,49 +321,75 @@ struct Tracer {
                     const TriRec tr = tri_unpack(q0, q1, q2);
                     t_leaf = tri_intersect(tr.a, tr.ab, tr.ac, (tr.obj_cull >> 31) != 0, w.o, w.d);
                 }
-                leaf_pop = true;
+                need_pop = true;
                 if(t_leaf >= 0.0f) {
                     if((w.dest & PT_DEST_SHADOW) && t_leaf < w.thr) {
                         w.occluded = true;
-                        leaf_pop = false;
+                        need_pop = false;
                     }
                     else {
                         if(w.best_ref == PT_REF_NONE || !(w.best_t < t_leaf)) {
                             w.best_t = t_leaf;
                             w.best_ref = cur;
                         }
-                        w.t_max = fmin_std(w.t_max, t_leaf);
+                        w.set_t_max(fmin_std(w.t_max, t_leaf));
                     }
                 }
                 cur = PT_REF_NONE;
             }
-            pop_mask |= __ballot(leaf_pop);
         }
-        // pop: the first parked node whose entry distance is still below t_max (scene.cpp:137: re-tested against the then-current distance)
-        if(pop_mask != 0ULL) {
-            bool need_pop = lane_of(pop_mask);
+        // pop: the first parked node whose entry distance is still below t_max (scene.cpp:137: re-tested against the then-current distance);
+        // the sentinel at the bottom passes the test and ends the walk
+        if(__ballot(need_pop) != 0ULL) {
             uint32_t sp = w.sp;
             const float t_max = w.t_max;
-            while(__ballot(need_pop & (sp > 0u)) != 0ULL) {
-                if(need_pop & (sp > 0u)) {
+            while(__ballot(need_pop) != 0ULL) {
+                if(need_pop) {
                     sp--;
                     const uint32_t slot = (sp & (uint32_t)(STACK_LDS - 1)) * 256u;
                     const u2v e = stack_l[slot];
                     if(sp >= (uint32_t)STACK_LDS) {
-                        stack_l[slot] = my_spill[sp - STACK_LDS];
+                        stack_l[slot] = my_spill[sp - STACK_LDS]; // the window moves down: the entry that left it last comes back
                     }
                     if(__uint_as_float(e.y) < t_max) {
                         cur = e.x;
                         need_pop = false;
+                        moved = true;
                     }
                 }
             }
             w.sp = sp;
         }
         w.cur = cur;
-        if(lane_of(node_mask | leaf_mask) & (cur != PT_REF_NONE)) {
+        if(moved & (cur != PT_REF_NONE)) {
             fetch(cur, R);
         }
+    }
+
+    // One step of the wavefront: the common step for the lanes on inner nodes; then, if no lane is left on one or `leaf_min` lanes wait for
+    // it, the rare one.  Returns false when no lane of the wavefront stands anywhere any more.
+    PT_D bool step(Walk &w, Rec &R, int leaf_min, uint32_t &n_nodes, uint32_t &n_leaves) const {
+        PT_STAMP(0); // loop back, the caller's code between two steps
+        PT_STAMP(7); // (nothing: what a stamp costs)
+        const unsigned long long nodes = node_lanes(w.cur), slow = slow_lanes(w.cur);
+        if((nodes | slow) == 0ULL) {
+            return false;
+        }
+        PT_STAMP(1); // classification
+        if(nodes != 0ULL) {
+            n_nodes += (uint32_t)__popcll(nodes);
+            node_step(w, R, nodes, nodes & __builtin_amdgcn_uicmp(w.sp, (uint32_t)STACK_LDS, 35));
+        }
+        PT_STAMP(5); // leaving the common step
+        // The rare step, for the leaves and the walks that have to go on popping: its code is long (a triangle test is 100 instructions,
+        // a division among them), so the waiting lanes share it -- not before `leaf_min` of them wait, unless no lane stands on a node any
+        // more.  (Serving the popping walks at once instead of letting them wait with the leaves: 422 against 430 Msamples/s.)
+        if(slow != 0ULL && (nodes == 0ULL || __popcll(slow) >= leaf_min)) {
+            // (slow was taken before the common step: a lane that has just reached a leaf is not in it, its record is on its way)
+            slow_step(w, R, slow & __builtin_amdgcn_uicmp(w.cur, PT_REF_POPPING, 36), n_leaves);
+        }
+        PT_STAMP(6); // the rare step (or the test for it)
+        return true;
     }
 };
 
@@ -942,8 +983,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     at += (size_t)PT_LDS_TABLE_MAX * 6 * sizeof(float4);
     float4 *materials_l = reinterpret_cast<float4 *>(at);
     at += (size_t)PT_LDS_TABLE_MAX * 4 * sizeof(float4);
-    float4 *lds_pairs = reinterpret_cast<float4 *>(at);
-    float4 *lds_tris = lds_pairs + 4 * (size_t)A->sc.n_lds_pairs;
+    float4 *lds_recs = reinterpret_cast<float4 *>(at); // (small scenes) every record, in the order of `recs`
 
     ShadeTables tb;
     tb.emis.cdf_l = (const float __attribute__((address_space(3))) *)cdf_l;
@@ -977,13 +1017,10 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     }
 
     if(IN_LDS) {
-        const uint32_t n_lds_pairs = A->sc.n_lds_pairs, n_lds_tris = A->sc.n_lds_tris;
-        const float4 *src_pairs = A->sc.pairs, *src_tris = A->sc.tris;
-        for(uint32_t i = tid; i < 4 * n_lds_pairs; i += 256) {
-            lds_pairs[i] = src_pairs[i];
-        }
-        for(uint32_t i = tid; i < PT_TRI_QUADS * (n_lds_tris + 1 + A->sc.n_spheres); i += 256) { // triangles, the spare record, spheres (pt_types.h)
-            lds_tris[i] = src_tris[i];
+        const uint32_t n_lds_quads = 4u * (A->sc.pair_base + A->sc.n_pairs);
+        const float4 *src_recs = A->sc.recs;
+        for(uint32_t i = tid; i < n_lds_quads; i += 256) {
+            lds_recs[i] = src_recs[i];
         }
     }
     for(uint32_t i = lane; i < n_slots; i += 64) {
@@ -995,15 +1032,11 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
 
     Tracer<STACK_LDS, IN_LDS> tr;
     if(IN_LDS) {
-        tr.pairs = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_pairs;
-        tr.tris = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_tris;
+        tr.recs = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_recs;
     }
     else {
-        tr.pairs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)A->sc.pairs;
-        tr.tris = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)A->sc.tris;
+        tr.recs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)A->sc.recs;
     }
-    tr.sphere_base = A->sc.n_tris + 1u;
-    tr.prefetch = A->prefetch != 0;
     tr.stack_l = stack_l;
     tr.my_spill = (glb_u2_ptr)(A->spill + ((size_t)wave * 64 + lane) * A->spill_depth);
 
@@ -1028,13 +1061,12 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     w.dest = 0;
     w.best_t = 0.0f;
     w.best_ref = PT_REF_NONE;
-    w.t_max = FLT_MAX;
+    w.set_t_max(FLT_MAX);
     w.cur = PT_REF_NONE;
     w.sp = 0;
     w.occluded = false;
     typename Tracer<STACK_LDS, IN_LDS>::Rec rec;
     rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-    rec.warm = 0;
     float4 win_o = make_float4(0, 0, 0, 0), win_d = make_float4(0, 0, 0, __uint_as_float(PT_DEST_NULL)); // the lane's ray of the ring's window
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, n_shadow = 0, n_samples = 0, n_vertices = 0;
     uint32_t w_steps = 0, w_passes = 0; // wave-level diagnostics (same value in every lane)
@@ -1102,7 +1134,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                 w.dest = sv[7 * st];
                 w.best_t = __uint_as_float(sv[8 * st]);
                 w.best_ref = sv[9 * st];
-                w.t_max = __uint_as_float(sv[10 * st]);
+                w.set_t_max(__uint_as_float(sv[10 * st]));
                 w.cur = sv[11 * st];
                 const uint32_t packed = sv[12 * st];
                 w.sp = packed & 0x7fffffffu;
@@ -1126,8 +1158,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
             }
             // the record registers do not live across a shading pass: walks in progress fetch theirs again
             rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-    rec.warm = 0;
-            if(active && w.cur != PT_REF_NONE) {
+                    if(active && w.cur < PT_REF_POPPING) { // (a walk that is over or about to pop stands on no record)
                 tr.fetch(w.cur, rec);
             }
         }
@@ -1213,15 +1244,12 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
 #endif
 #pragma unroll 1
             for(int burst = 0; burst < burst_steps; burst++) {
-                // (a reference with bit 31 set is a leaf -- or PT_REF_NONE, which is excluded first)
-                const unsigned long long standing_mask = __ballot(active) & __builtin_amdgcn_uicmp(w.cur, PT_REF_NONE, 33);
-                const unsigned long long leaf_mask = standing_mask & __builtin_amdgcn_sicmp((int)w.cur, 0, 40), node_mask = standing_mask & ~leaf_mask;
-                if((leaf_mask | node_mask) == 0ULL) {
+                // (a lane without a walk in progress has cur == PT_REF_NONE: retire leaves it there, and nothing else changes it)
+                w_steps++;
+                if(!tr.step(w, rec, leaf_min, n_nodes, n_leaves)) {
+                    w_steps--;
                     break;
                 }
-                const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
-                w_steps++;
-                tr.step(w, rec, node_mask, do_leaves ? leaf_mask : 0ULL, n_nodes, n_leaves);
             }
 #ifdef PT_PATH_TIMING
             t_burst += __builtin_amdgcn_s_memtime() - t_b0;
@@ -1265,28 +1293,20 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     lds_u2_ptr stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(lds_raw) + tid;
-    float4 *lds_pairs = reinterpret_cast<float4 *>(lds_raw + (size_t)STACK_LDS * 256 * sizeof(uint2));
-    float4 *lds_tris = lds_pairs + 4 * (size_t)sc.n_lds_pairs;
+    float4 *lds_recs = reinterpret_cast<float4 *>(lds_raw + (size_t)STACK_LDS * 256 * sizeof(uint2));
     if(IN_LDS) {
-        for(uint32_t i = tid; i < 4 * sc.n_lds_pairs; i += 256) {
-            lds_pairs[i] = sc.pairs[i];
-        }
-        for(uint32_t i = tid; i < PT_TRI_QUADS * (sc.n_lds_tris + 1 + sc.n_spheres); i += 256) {
-            lds_tris[i] = sc.tris[i];
+        for(uint32_t i = tid; i < 4u * (sc.pair_base + sc.n_pairs); i += 256) {
+            lds_recs[i] = sc.recs[i];
         }
         __syncthreads();
     }
     Tracer<STACK_LDS, IN_LDS> tr;
     if(IN_LDS) {
-        tr.pairs = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_pairs;
-        tr.tris = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_tris;
+        tr.recs = (typename RecPtr<IN_LDS>::type)(lds_f4_cptr)lds_recs;
     }
     else {
-        tr.pairs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.pairs;
-        tr.tris = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.tris;
+        tr.recs = (typename RecPtr<IN_LDS>::type)(glb_f4_cptr)sc.recs;
     }
-    tr.sphere_base = sc.n_tris + 1u;
-    tr.prefetch = prefetch != 0;
     tr.stack_l = stack_l;
     const size_t gid = (size_t)blockIdx.x * 256 + tid;
     tr.my_spill = (glb_u2_ptr)(spill + gid * spill_depth);
@@ -1297,7 +1317,6 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
     Walk w;
     typename Tracer<STACK_LDS, IN_LDS>::Rec rec;
     rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-    rec.warm = 0;
     RootBox root;
     root.ref = sc.root_ref;
     for(int k = 0; k < 3; k++) {
@@ -1306,13 +1325,7 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
     }
     tr.start(w, rec, root, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
     uint32_t n_nodes = 0, n_leaves = 0;
-    for(;;) {
-        const unsigned long long standing_mask = __builtin_amdgcn_uicmp(w.cur, PT_REF_NONE, 33);
-        const unsigned long long leaf_mask = standing_mask & __builtin_amdgcn_sicmp((int)w.cur, 0, 40), node_mask = standing_mask & ~leaf_mask;
-        if((leaf_mask | node_mask) == 0ULL) {
-            break;
-        }
-        tr.step(w, rec, node_mask, leaf_mask, n_nodes, n_leaves);
+    while(tr.step(w, rec, 1, n_nodes, n_leaves)) {
     }
     out[gid] = make_uint2(__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref);
 }
@@ -1329,10 +1342,7 @@ __global__ __launch_bounds__(256) void pt_steptime_kernel(PtDevScene sc, const f
     const uint32_t lane = (uint32_t)tid & 63u;
     const uint32_t wave = blockIdx.x * 4u + ((uint32_t)tid >> 6);
     Tracer<STACK_LDS, false> tr;
-    tr.pairs = (glb_f4_cptr)sc.pairs;
-    tr.tris = (glb_f4_cptr)sc.tris;
-    tr.sphere_base = sc.n_tris + 1u;
-    tr.prefetch = prefetch != 0;
+    tr.recs = (glb_f4_cptr)sc.recs;
     tr.stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(lds_raw) + tid;
     const size_t gid = (size_t)blockIdx.x * 256 + tid;
     tr.my_spill = (glb_u2_ptr)(spill + gid * spill_depth);
@@ -1344,7 +1354,6 @@ __global__ __launch_bounds__(256) void pt_steptime_kernel(PtDevScene sc, const f
     Walk w;
     typename Tracer<STACK_LDS, false>::Rec rec;
     rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-    rec.warm = 0;
     RootBox root;
     root.ref = sc.root_ref;
     for(int k = 0; k < 3; k++) {
@@ -1353,15 +1362,13 @@ __global__ __launch_bounds__(256) void pt_steptime_kernel(PtDevScene sc, const f
     }
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const unsigned long long t_again = __builtin_amdgcn_s_memtime();
+#ifdef PT_STEP_STAMPS
+    tr.stamp_last = t_again;
+#endif
     tr.start(w, rec, root, make_float4(r[0], r[1], r[2], 0.0f), make_float4(r[3], r[4], r[5], __uint_as_float(0u)));
     uint32_t n_nodes = 0, n_leaves = 0, steps = 0;
     unsigned long long waiting = 0;
     for(;;) {
-        const unsigned long long standing_mask = __builtin_amdgcn_uicmp(w.cur, PT_REF_NONE, 33);
-        const unsigned long long leaf_mask = standing_mask & __builtin_amdgcn_sicmp((int)w.cur, 0, 40), node_mask = standing_mask & ~leaf_mask;
-        if((leaf_mask | node_mask) == 0ULL) {
-            break;
-        }
         if(STAMP) {
             const unsigned long long t1 = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1369,11 +1376,20 @@ __global__ __launch_bounds__(256) void pt_steptime_kernel(PtDevScene sc, const f
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             waiting += t2 - t1;
         }
+        if(!tr.step(w, rec, 1, n_nodes, n_leaves)) {
+            break;
+        }
         steps += 1u;
-        tr.step(w, rec, node_mask, leaf_mask, n_nodes, n_leaves);
     }
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     out[ray] = make_uint4(steps, (uint32_t)waiting, (uint32_t)(t_end - t_begin), (uint32_t)(t_again - t_begin));
+#ifdef PT_STEP_STAMPS
+    // (the stamped build reports its segments behind the n results: 8 x 8 bytes per ray)
+    unsigned long long *seg = reinterpret_cast<unsigned long long *>(out + n) + 8 * (size_t)ray;
+    for(int k = 0; k < 8; k++) {
+        seg[k] = tr.stamp_acc[k];
+    }
+#endif
 }
 
 // ---- diagnostic: the traversal alone on the rays of a finished render ----------------------------------------------------------------
@@ -1394,10 +1410,7 @@ __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, Pt
         return;
     }
     Tracer<STACK_LDS, false> tr;
-    tr.pairs = (glb_f4_cptr)sc.pairs;
-    tr.tris = (glb_f4_cptr)sc.tris;
-    tr.sphere_base = sc.n_tris + 1u;
-    tr.prefetch = prefetch != 0;
+    tr.recs = (glb_f4_cptr)sc.recs;
     tr.stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(lds_raw) + tid;
     tr.my_spill = (glb_u2_ptr)(spill + ((size_t)wave * 64 + lane) * spill_depth);
     RootBox root;
@@ -1432,13 +1445,12 @@ __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, Pt
     w.dest = 0;
     w.best_t = 0.0f;
     w.best_ref = PT_REF_NONE;
-    w.t_max = FLT_MAX;
+    w.set_t_max(FLT_MAX);
     w.cur = PT_REF_NONE;
     w.sp = 0;
     w.occluded = false;
     typename Tracer<STACK_LDS, false>::Rec rec;
     rec.r0 = rec.r1 = rec.r2 = rec.r3 = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-    rec.warm = 0;
     uint32_t n_nodes = 0, n_leaves = 0, n_rays = 0, checksum = 0, w_steps = 0;
     for(;;) {
         if(active && w.cur == PT_REF_NONE) {
@@ -1472,14 +1484,11 @@ __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, Pt
         }
 #pragma unroll 1
         for(int burst = 0; burst < burst_steps; burst++) {
-            const unsigned long long standing_mask = __ballot(active) & __builtin_amdgcn_uicmp(w.cur, PT_REF_NONE, 33);
-            const unsigned long long leaf_mask = standing_mask & __builtin_amdgcn_sicmp((int)w.cur, 0, 40), node_mask = standing_mask & ~leaf_mask;
-            if((leaf_mask | node_mask) == 0ULL) {
+            w_steps++;
+            if(!tr.step(w, rec, leaf_min, n_nodes, n_leaves)) {
+                w_steps--;
                 break;
             }
-            const bool do_leaves = node_mask == 0ULL || __popcll(leaf_mask) >= leaf_min;
-            w_steps++;
-            tr.step(w, rec, node_mask, do_leaves ? leaf_mask : 0ULL, n_nodes, n_leaves);
         }
     }
     for(int off = 32; off > 0; off >>= 1) {
@@ -1523,7 +1532,7 @@ int occupancy(size_t lds_bytes) {
 
 template<int STACK_LDS, bool IN_LDS>
 void launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg) {
-    const size_t lds = (size_t)STACK_LDS * 256 * sizeof(uint2) + (IN_LDS ? (size_t)scene.n_lds_pairs * 64 + ((size_t)scene.n_lds_tris + 1 + scene.n_spheres) * 64 : 0);
+    const size_t lds = (size_t)STACK_LDS * 256 * sizeof(uint2) + (IN_LDS ? ((size_t)scene.n_lds_pairs + scene.pair_base) * 64 : 0);
     hipLaunchKernelGGL((pt_closest_kernel<STACK_LDS, IN_LDS>), dim3((n + 255) / 256), dim3(256), lds, stream, scene, rays6, n, out, cfg.spill, cfg.spill_depth, cfg.prefetch);
 }
 

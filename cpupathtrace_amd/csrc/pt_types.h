@@ -24,8 +24,12 @@
 //                                     sphere:   (origin.xyz, radius) (0) (0, bits ref, 0, bits material) (emission rgba)
 //   emis_cdf  float[n_emis]         normalised inclusive prefix sums (scene.cpp:169-180)
 //
-// Child / object reference (32 bits): bit 31 = leaf; leaf: bit 30 = sphere, bits 0..29 = index into tris / spheres;
-// inner: index of the child's own pair record.  PT_REF_NONE marks "no node".
+// Child / object reference (32 bits): bit 31 = leaf; leaf: bit 30 = sphere; PT_REF_NONE marks "no node".
+// The references INSIDE the tree (the two of every pair record, root_ref, and therefore every hit the traversal reports) carry in their low
+// 30 bits the index of the referenced record in ONE array `recs` = [leaf records `tris` | pair records `pairs`]: triangle t = t,
+// sphere i = n_tris + 1 + i, inner node with pair slot p = pair_base + p -- so a walk fetches the record it stands on with one shift
+// and one add whatever it is.  (pt_scene_create builds the two arrays with local indices and links them: pt_link_records.)
+// Consumers of a hit: triangle index = low bits; sphere index = low bits - (n_tris + 1).
 #ifndef PT_TYPES_H
 #define PT_TYPES_H
 
@@ -42,8 +46,9 @@
 #define PT_MAX_DEPTH 128    /* deepest supported BVH */
 
 struct PtDevScene {
-    const float4 *pairs;
-    const float4 *tris;
+    const float4 *recs;  /* leaf records, then pair records: what the tree's references index */
+    const float4 *pairs; /* = recs + 4 * pair_base */
+    const float4 *tris;  /* = recs */
     const float4 *tri_shade;
     const float4 *spheres;
     const uint2 *sph_meta;
@@ -54,6 +59,7 @@ struct PtDevScene {
     float root_lo[3];
     float root_hi[3];
     uint32_t root_ref; /* reference of the root node (a leaf when the scene has one object) */
+    uint32_t pair_base; /* record index of pair slot 0: n_tris + 1 + n_spheres rounded up to even (siblings share a 128-byte line) */
     uint32_t n_pairs;
     uint32_t n_tris;
     uint32_t n_spheres;

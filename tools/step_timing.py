@@ -24,14 +24,21 @@ def rays_through(x0, x1, y0, y1, n):
     return np.ascontiguousarray(np.concatenate([np.tile(np.array([0.0, 0.0, -3.0]), (n, 1)), d], axis=1), dtype=np.float32)
 
 
-def run(rays, lanes, flags):
-    out = np.zeros((len(rays), 4), np.uint32)
-    assert fn(s._h, rays.ctypes.data, len(rays), lanes, flags, out.ctypes.data) == 0, binding.load().pt_last_error()
-    return out.astype(np.float64)
+SEGMENTS = ["between two steps", "classification", "waiting for the record", "slab tests, decision, stack", "address + request of the next record",
+            "leaving the common step", "the rare step or the test for it", "(two stamps back to back)"]
+
+
+def run(rays, lanes, flags, segments=False):
+    n = len(rays)
+    out = np.zeros(20 * n, np.uint32)
+    assert fn(s._h, rays.ctypes.data, n, lanes, flags, out.ctypes.data) == 0, binding.load().pt_last_error()
+    if segments:
+        return out[4 * n:].view(np.uint64).reshape(n, 8).astype(np.float64)
+    return out[:4 * n].reshape(n, 4).astype(np.float64)
 
 
 for label, win in (("window on the mesh", (-0.05, 0.05, -0.21, -0.11)), ("whole frame", (-0.33, 0.33, -0.33, 0.33))):
-    for n, lanes in ((256, 1), (1024, 1), (4096, 1), (16384, 1), (4096, 64), (262144, 64)):
+    for n, lanes in ((256, 1), (4096, 1), (4096, 64), (262144, 64)):
         rays = rays_through(*win, n)
         for pf in (0, 1):
             run(rays, lanes, pf)
@@ -42,6 +49,12 @@ for label, win in (("window on the mesh", (-0.05, 0.05, -0.21, -0.11)), ("whole 
             steps = clean[:, 0].reshape(waves, -1).max(axis=1).sum() if lanes > 1 else clean[:, 0].sum()
             total = clean[:, 2].reshape(waves, -1).max(axis=1).sum() if lanes > 1 else clean[:, 2].sum()
             wait = stamped[:, 1].reshape(waves, -1).max(axis=1).sum() if lanes > 1 else stamped[:, 1].sum()
+            if lanes == 1 and pf == 0 and os.environ.get("PT_STEP_STAMPS"):
+                seg = run(rays, lanes, pf, segments=True)
+                st = clean[:, 0].sum()
+                price = seg[:, 7].sum() / st
+                print("    stamped build, cycles per step (a stamp's own round trip, %.0f, taken off each): " % price +
+                      "; ".join("%s %.0f" % (SEGMENTS[k], seg[:, k].sum() / st - price) for k in range(7)), flush=True)
             print("%-18s %6d rays, %2d per wavefront, %5d wavefronts (%4.1f per SIMD), prefetch %d: %5.1f steps per walk, %6.0f cycles per step; stamped run: %5.0f of them waiting for the record" % (
                 label, n, lanes, waves, min(waves / 1024.0, 8.0), pf, steps / waves, total / steps, wait / steps), flush=True)
 s.close()

@@ -168,7 +168,7 @@ struct pt_scene {
     PtPathConfig path_cfg{};
     int path_blocks_per_cu = 0;
     uint32_t path_slots = 0, path_waves = 0, path_cap = 0;
-    DevBuf<uint32_t> sl_stream, pull_counter, tile_left;
+    DevBuf<uint32_t> sl_stream, sl_nee_mask, pull_counter, tile_left;
     DevBuf<int4> sl_rect, st_rect;
     DevBuf<int32_t> sl_cursor, sl_path_length;
     DevBuf<uint64_t> sl_rng, st_rng;
@@ -250,11 +250,13 @@ int derive_options(const pt_options *o, PtDevOptions *out) {
     d.candidate_batch_count = std::max(std::max(o->min_sample_count, o->max_sample_count / 4) / d.stats_sample_count, 2);
     d.check_sample_count =
       std::min(std::max({o->min_sample_count / 2, (o->max_sample_count - o->min_sample_count) / 8, 8, d.stats_sample_count}), 1024) / d.stats_sample_count;
-    // closed candidates a pixel can accumulate (worker.cpp:214-222)
+    // closed candidates a pixel can accumulate (worker.cpp:214-222).  A candidate closes after candidate_batch_count >= max / (4 S) batches
+    // and a pixel has at most max / S of them, so at most 4 candidates ever close: the check below is a guard against a change of the
+    // formulas above, not a limit a caller can reach (PT_MAX_CANDIDATES = 8).
     const int batches = std::max(o->max_sample_count, 0) / d.stats_sample_count;
     const int closed = batches > 0 ? (batches - 1) / d.candidate_batch_count : 0;
     if(closed > PT_MAX_CANDIDATES) {
-        return fail(PT_ERR_UNSUPPORTED, "sample counts give more than 8 estimator candidates per pixel");
+        return fail(PT_ERR_UNSUPPORTED, "internal: the estimator's constants allow more than 8 closed candidates per pixel (worker.cpp:158-164 give at most 4)");
     }
     *out = d;
     return PT_OK;
@@ -375,6 +377,7 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     PT_HIP(s->sl_bounce_pd.ensure(total));
     PT_HIP(s->sl_path_length.ensure(total));
     PT_HIP(s->sl_nee.ensure(static_cast<size_t>(total) * std::max<uint32_t>(rays_per_slot - 1U, 1U)));
+    PT_HIP(s->sl_nee_mask.ensure(total));
     PT_HIP(s->sl_est.ensure(total));
     PT_HIP(s->sl_cand.ensure(static_cast<size_t>(total) * PT_MAX_CANDIDATES));
     PT_HIP(s->lq_ray_o.ensure(static_cast<size_t>(waves) * cap));
@@ -435,6 +438,7 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     S.bounce_pd = s->sl_bounce_pd.ptr;
     S.path_length = s->sl_path_length.ptr;
     S.nee = reinterpret_cast<float4 *>(s->sl_nee.ptr);
+    S.nee_mask = s->sl_nee_mask.ptr;
     S.est = s->sl_est.ptr;
     S.cand = s->sl_cand.ptr;
     PtLocalQueue Q{};
@@ -760,7 +764,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         s->build_ms[2] = built.build_ms;
         s->depth = built.depth;
         if(s->depth > PT_MAX_DEPTH) {
-            return fail(PT_ERR_UNSUPPORTED, "BVH deeper than 128 levels");
+            return fail(PT_ERR_UNSUPPORTED, "internal: BVH deeper than 128 levels (impl::constructBVH keeps a child at two thirds of its parent at most: 53 levels for 2^30 objects; tests/test_oracle_golden.py)");
         }
         n_pairs = built.n_pairs;
         root_ref = built.root_ref;
@@ -827,7 +831,7 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
         s->tree = ptb::build_reference_bvh(boxes, threads);
         s->depth = s->tree.depth;
         if(s->depth > PT_MAX_DEPTH) {
-            return fail(PT_ERR_UNSUPPORTED, "BVH deeper than 128 levels");
+            return fail(PT_ERR_UNSUPPORTED, "internal: BVH deeper than 128 levels (impl::constructBVH keeps a child at two thirds of its parent at most: 53 levels for 2^30 objects; tests/test_oracle_golden.py)");
         }
         ptb::FlatBvh flat = ptb::flatten_breadth_first(s->tree, leaf_ref, align_siblings);
         n_pairs = flat.n_pairs;
@@ -967,7 +971,8 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     const int emissive_object_count = static_cast<int>(cdf.size());
     const int object_sample_count = std::min(2 + static_cast<int>(std::log10(emissive_object_count + 1)), emissive_object_count); // scene.cpp:226
     if(d->n_point_lights + static_cast<uint32_t>(object_sample_count) > PT_MAX_NEE) {
-        return fail(PT_ERR_UNSUPPORTED, "more than 8 light samples per path vertex");
+        return fail(PT_ERR_UNSUPPORTED, "more than 32 light samples per path vertex (" + std::to_string(d->n_point_lights) + " point lights + " + std::to_string(object_sample_count) +
+                                        " emitter samples): the visibility mask of a path vertex has 32 bits");
     }
 
     // ---- upload --------------------------------------------------------------------------------------------------------------

@@ -47,7 +47,8 @@ struct PtSlots {
     double *divisor;       // sample_divisor (worker.cpp:39)
     double *bounce_pd;     // sample_bounce_pd (worker.cpp:40)
     int32_t *path_length;  // worker.cpp:43
-    float4 *nee;           // [PT_MAX_NEE][total] weighed_spectrum of the pending shadow rays (worker.cpp:97)
+    float4 *nee;           // [light samples per vertex][total] weighed_spectrum of the pending shadow rays (worker.cpp:97)
+    uint32_t *nee_mask;    // which of them wait for their shadow ray (or needed none): bit per light sample
     PtEstimator *est;      // per-pixel estimator (worker.cpp:172-192)
     PtCandidate *cand;     // [total][PT_MAX_CANDIDATES]
 };

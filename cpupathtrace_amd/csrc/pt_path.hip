@@ -393,15 +393,20 @@ struct Tracer {
     }
 };
 
-// ---- the per-slot word in LDS ---------------------------------------------------------------------------------------------------------
-// bits 0..7   visibility of the last vertex's light samples (1 = unoccluded), set by the lanes that finish the shadow rays
-// bits 8..15  rays of the slot still in the queue or being walked
-// bits 16..23 PT_F_* flags of the slot
-// bits 24..31 light samples of the last vertex whose contribution waits in S.nee for its shadow ray (or needed none)
-#define PT_W_PENDING(word) (((word) >> 8) & 0xffu)
-#define PT_W_FLAGS(word) (((word) >> 16) & 0xffu)
-#define PT_W_NEE(word) ((word) >> 24)
-#define PT_W_ONE_RAY 0x100u
+// ---- the per-slot word in LDS (64 bits) --------------------------------------------------------------------------------------------------
+// bits 0..31  visibility of the last vertex's light samples (1 = unoccluded), set by the lanes that finish the shadow rays
+// bits 32..39 rays of the slot still in the queue or being walked
+// bits 40..47 PT_F_* flags of the slot
+// A lane that finishes a shadow ray adds (visibility bit) - (one ray) with ONE 64-bit LDS atomic.  Which light samples of the last vertex
+// have a contribution waiting in S.nee is kept with the slot's state in HBM (S.nee_mask): only the shading pass needs it.
+// Scene::sampleLights has no upper bound on the samples per vertex (every LightSource + min(2 + log10(E + 1), E) emitters, scene.cpp:226,231);
+// the 32 bits of the visibility mask are this kernel's (PT_MAX_NEE).
+typedef unsigned long long __attribute__((address_space(3))) *lds_u64_ptr;
+#define PT_W_VIS(word) ((uint32_t)(word))
+#define PT_W_PENDING(word) ((uint32_t)((word) >> 32) & 0xffu)
+#define PT_W_FLAGS(word) ((uint32_t)((word) >> 40) & 0xffu)
+#define PT_W_ONE_RAY (1ULL << 32)
+#define PT_W_MAKE(flags, rays, vis) (((unsigned long long)(flags) << 40) | ((unsigned long long)(rays) << 32) | (unsigned long long)(vis))
 
 #define PT_DEST_SLOT_MASK 0xffffu
 #define PT_DEST_J_SHIFT 16
@@ -469,15 +474,15 @@ struct ShadeTables {
 // New rays go to the wave's ring: extension rays first, then the shadow rays light sample by light sample (ballot + prefix popcount
 // give every lane its position; rays of one kind from neighbouring pixels end up in neighbouring lanes of the traversal).
 PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOptions &opt, const PtSlots &S, const PtStreams &T, const PtLocalQueue &Q,
-                    WaveCtx &ctx, uint32_t row, uint32_t lane, size_t slot_base, size_t queue_base, lds_u32_ptr word_l, lds_u2_ptr hit_l,
+                    WaveCtx &ctx, uint32_t row, uint32_t lane, size_t slot_base, size_t queue_base, lds_u64_ptr word_l, lds_u2_ptr hit_l,
                     float4 *__restrict__ image, PtDevCounters *counters, const ShadeTables &tb, uint32_t &n_samples, uint32_t &n_vertices) {
     const uint32_t ls = row * 64 + lane; // slot of the wave
     const size_t p = slot_base + ls;     // slot of the grid
     const unsigned long long lt = (1ULL << lane) - 1ULL;
     const uint32_t n_light_samples = sc.n_lights + sc.n_object_samples;
-    const uint32_t word = word_l[ls];
+    const unsigned long long word = word_l[ls];
     uint32_t flags = PT_W_FLAGS(word);
-    const uint32_t vis_bits = word & 0xffu;
+    const uint32_t vis_bits = PT_W_VIS(word);
     bool ready = !(flags & PT_F_DONE) && PT_W_PENDING(word) == 0;
     if(__ballot(ready) == 0ULL) {
         return;
@@ -550,7 +555,7 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
             else if(want) {
                 flags = PT_F_DONE;
                 ready = false;
-                word_l[ls] = PT_F_DONE << 16;
+                word_l[ls] = PT_W_MAKE(PT_F_DONE, 0u, 0u);
             }
             ctx.n_dead += (uint32_t)__popcll(__ballot(want && !got));
         }
@@ -581,7 +586,7 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
             // state, and -- a single word, to bring the line into the caches -- the shading record of the triangle that was hit, which
             // is the one access of this pass that usually comes from HBM.
             const float4 out4 = S.out[p];
-            uint32_t mask = PT_W_NEE(word);
+            uint32_t mask = S.nee_mask[p];
             // the first two light samples (most scenes have no more) are fetched with the batch, the others one by one below
             const uint32_t lit = mask & vis_bits;
             float4 nee0 = make_float4(0, 0, 0, 0), nee1 = make_float4(0, 0, 0, 0);
@@ -923,7 +928,8 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
         n_rays++;
     }
     if(alive) {
-        word_l[ls] = (nee_out_mask << 24) | (flags << 16) | (n_rays << 8) | vis_init;
+        word_l[ls] = PT_W_MAKE(flags, n_rays, vis_init);
+        S.nee_mask[p] = nee_out_mask;
         S.rng[p] = rng;
         S.cursor[p] = cursor;
         if(flags & PT_F_IN_FLIGHT) {
@@ -973,8 +979,8 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     at += (size_t)STACK_LDS * 256 * sizeof(uint2);
     lds_u2_ptr hit_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(at) + wave_in_block * n_slots;
     at += (size_t)4 * n_slots * sizeof(uint2);
-    lds_u32_ptr word_l = (lds_u32_ptr)reinterpret_cast<uint32_t *>(at) + wave_in_block * n_slots;
-    at += (size_t)4 * n_slots * sizeof(uint32_t);
+    lds_u64_ptr word_l = (lds_u64_ptr)reinterpret_cast<unsigned long long *>(at) + wave_in_block * n_slots;
+    at += (size_t)4 * n_slots * sizeof(unsigned long long);
     float *cdf_l = reinterpret_cast<float *>(at);
     at += (size_t)PT_LDS_TABLE_MAX * sizeof(float);
     float4 *emis_l = reinterpret_cast<float4 *>(at);
@@ -1026,7 +1032,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     for(uint32_t i = lane; i < n_slots; i += 64) {
         // no stream, nothing pending: ready to take a stream.  (A small job uses only the first slots of every wavefront: its streams are
         // spread over all the wavefronts the chip holds, because a stream's samples are sequential and only more wavefronts shorten the chain.)
-        word_l[i] = i < (uint32_t)slots_per_wave ? 0u : (PT_F_DONE << 16);
+        word_l[i] = i < (uint32_t)slots_per_wave ? 0ULL : PT_W_MAKE(PT_F_DONE, 0u, 0u);
     }
     __syncthreads(); // the only barrier: from here on the four wavefronts of the workgroup never wait for each other
 
@@ -1169,14 +1175,14 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
             if(active && w.cur == PT_REF_NONE) {
                 const uint32_t ls = w.dest & PT_DEST_SLOT_MASK;
                 if(w.dest & PT_DEST_SHADOW) {
-                    const uint32_t j = (w.dest >> PT_DEST_J_SHIFT) & 7u;
+                    const uint32_t j = (w.dest >> PT_DEST_J_SHIFT) & 31u;
                     // one ray less pending; an unoccluded light sample sets its visibility bit
-                    __hip_atomic_fetch_add(&word_l[ls], (w.occluded ? 0u : (1u << j)) - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&word_l[ls], (unsigned long long)(w.occluded ? 0u : (1u << j)) - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 else {
                     const u2v h = {__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref};
                     hit_l[ls] = h;
-                    __hip_atomic_fetch_add(&word_l[ls], 0u - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&word_l[ls], 0ULL - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 active = false;
             }
@@ -1189,7 +1195,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                     // slots whose rays have all come back (or that wait for a stream)
                     uint32_t n_ready = 0;
                     for(uint32_t r = 0; r < (uint32_t)rows; r++) {
-                        const uint32_t word = word_l[r * 64 + lane];
+                        const unsigned long long word = word_l[r * 64 + lane];
                         n_ready += (uint32_t)__popcll(__ballot(!(PT_W_FLAGS(word) & PT_F_DONE) && PT_W_PENDING(word) == 0));
                     }
                     // enough of them for a pass: `min_ready`, or a share of the slots that are still alive -- a wavefront that is down to its
@@ -1616,7 +1622,7 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
 
 size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
     const size_t scene = ((size_t)n_lds_pairs + n_lds_leaf_records) * 64;
-    return (size_t)stack_lds * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + sizeof(uint32_t)) + PT_LDS_TABLE_BYTES + scene;
+    return (size_t)stack_lds * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + sizeof(unsigned long long)) + PT_LDS_TABLE_BYTES + scene;
 }
 
 int pt_path_blocks_per_cu(int stack_lds, int in_lds, size_t lds_bytes) {

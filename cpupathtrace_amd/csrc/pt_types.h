@@ -41,7 +41,7 @@
 #define PT_REF_NONE 0xffffffffu /* also: a leaf holding the NullObject of an empty scene */
 
 #define PT_TRI_QUADS 4      /* float4 per record of `tris` */
-#define PT_MAX_NEE 8        /* light samples per path vertex: point lights + object samples */
+#define PT_MAX_NEE 32       /* light samples per path vertex: point lights + object samples (bits of the visibility mask of a slot) */
 #define PT_MAX_CANDIDATES 8 /* closed candidates of the per-pixel estimator (worker.cpp:183-185) */
 #define PT_MAX_DEPTH 128    /* deepest supported BVH */
 

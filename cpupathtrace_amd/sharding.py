@@ -49,9 +49,10 @@ class ShardedJob:
     render_fn(tiles, image_tensor, want_stats) renders the given tiles into the (height, width, 4) float32 tensor on this
     rank's device; the default calls the HIP library.  Tests pass their own to exercise the sharding on CPU/gloo."""
 
-    def __init__(self, scene, camera, options, rank, world, device, base_seed=1234, render_fn=None, staged_gather=False):
+    def __init__(self, scene, camera, options, rank, world, device, base_seed=1234, render_fn=None, staged_gather=False, always_gather=False):
         """staged_gather: move the chunks through host memory around the gather (gloo has no device gather; used to rehearse the
-        N > 1 path with several ranks on ONE GPU -- RCCL wants one device per rank)."""
+        N > 1 path with several ranks on ONE GPU -- RCCL wants one device per rank).  always_gather: run the pack / gather / scatter
+        of the N > 1 path even in a world of one rank (tests/test_gpu_rccl.py: the collective executes on the device through RCCL)."""
         self.scene, self.camera, self.options = scene, camera, options
         self.staged_gather = staged_gather
         self.gather_bytes = 0
@@ -62,7 +63,8 @@ class ShardedJob:
         self.n_local_tiles = len(self.mine)
         self.image = torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=device)
         self.render_fn = render_fn or self._render_hip
-        if world > 1:
+        self.gathers = world > 1 or always_gather
+        if self.gathers:
             per_rank = [pixel_indices(local_tiles(self.tiles, r, world), self.width) for r in range(world)]
             self.chunk = max(len(p) for p in per_rank)
             self.my_index = torch.from_numpy(per_rank[rank]).to(device)
@@ -81,12 +83,13 @@ class ShardedJob:
     def render(self, want_stats=False):
         """Render this rank's tiles, then gather all tiles into rank 0's image.  Returns the render statistics of this rank."""
         stats = self.render_fn(self.mine, self.image, want_stats)
-        if self.world > 1:
+        if self.gathers:
             flat = self.image.view(-1, 4)
             self.send[: len(self.my_index)] = flat[self.my_index]
             dist.gather(self.send.cpu() if self.staged_gather else self.send, self.recv if self.rank == 0 else None, dst=0)
             if self.rank == 0:
-                for r in range(1, self.world):
+                # (rank 0's own tiles are in place already; with always_gather they are written again from what came back)
+                for r in range(0 if self.world == 1 else 1, self.world):
                     idx = self.all_index[r]
                     flat[idx] = self.recv[r][: len(idx)].to(flat.device)
         return stats

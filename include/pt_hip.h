@@ -128,7 +128,8 @@ const char *pt_last_error(void);
  * the device, level by level (pt_build.hip), for scenes of PT_BUILD_DEVICE_MIN (1024) objects and more, by the same recursion on the host
  * for smaller ones; the two produce the same tree bit for bit -- registers emissive objects (scene.cpp:183-208) and lays everything out
  * in device arrays on `device`.
- * PT_ERR_UNSUPPORTED: more than 8 light samples per path vertex (point lights + min(2 + log10(E + 1), E) object samples),
+ * PT_ERR_UNSUPPORTED: more than 32 light samples per path vertex (point lights + min(2 + log10(E + 1), E) object samples: Scene::sampleLights
+ * itself has no bound, scene.cpp:226,231; 32 are the bits of this library's per-vertex visibility mask),
  * or a BVH deeper than 128 levels.
  * Thread safety: calls on DIFFERENT scenes may run concurrently; render and intersection calls on the SAME scene are serialised inside
  * the library (one workspace per scene), so callers that run processItem from several threads on one Scene -- as the reference's

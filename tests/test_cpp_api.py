@@ -102,3 +102,73 @@ def test_reference_test_binary_on_gpu():
     r = _run(exe)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "11 tests, 0 failed" in r.stdout, r.stdout
+
+
+def _decode_png(path):
+    """A minimal PNG reader (8-bit RGB or RGBA, no interlace): width, height, channels, rows of bytes."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, width, height, channels = 8, b"", 0, 0, 0
+    while at < len(data):
+        n, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        if kind == b"IHDR":
+            width, height, depth, colour, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            assert depth == 8 and interlace == 0 and colour in (2, 6)
+            channels = 3 if colour == 2 else 4
+        elif kind == b"IDAT":
+            idat += body
+        at += 12 + n
+    raw = zlib.decompress(idat)
+    stride = width * channels
+    rows, prev = [], bytearray(stride)
+    for y in range(height):
+        f, line = raw[y * (stride + 1)], bytearray(raw[y * (stride + 1) + 1:(y + 1) * (stride + 1)])
+        for i in range(stride):
+            a = line[i - channels] if i >= channels else 0
+            b, c = prev[i], (prev[i - channels] if i >= channels else 0)
+            if f == 1:
+                line[i] = (line[i] + a) & 255
+            elif f == 2:
+                line[i] = (line[i] + b) & 255
+            elif f == 3:
+                line[i] = (line[i] + (a + b) // 2) & 255
+            elif f == 4:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                line[i] = (line[i] + (a if pa <= pb and pa <= pc else b if pb <= pc else c)) & 255
+        rows.append(bytes(line))
+        prev = line
+    return width, height, channels, rows
+
+
+@pytest.mark.gpu
+def test_reference_demo_on_gpu(tmp_path):
+    """demo/main.cpp of the reference, compiled UNCHANGED against this repository's headers (demo/main.cpp:47-241: BASELINE.json configs[0]'s
+    definition), run as a user would: the Cornell scene with the glass mesh (the stand-in written where the program looks for
+    assets/xyzrgb_dragon.obj, demo/main.cpp:149), a mirror sphere and a box, 256 x 256, 16..64 spp, thin-lens camera; processJob with its
+    progress callback, postProcess, io::writeRGBImage.  The PNG must be a 256 x 256 frame whose centre was hit (alpha > 0 -> a colour) and
+    the progress lines must run up to 100 %."""
+    import sys
+    exe = os.path.join(REF_OUT, "ref_demo")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_demo was not built (it is compiled from /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import write_standin_obj
+    assert write_standin_obj.write(str(tmp_path / "assets" / "xyzrgb_dragon.obj"), 300) == 179400
+    out_png = str(tmp_path / "out" / "demo.png")
+    r = subprocess.run([exe, out_png], cwd=str(tmp_path), env=dict(os.environ, PATHTRACE_SEED="1234"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "100.00% (64 / 64 tiles)" in r.stdout, r.stdout[-500:]
+    width, height, channels, rows = _decode_png(out_png)
+    assert (width, height) == (256, 256) and channels in (3, 4)
+    centre = rows[128][128 * channels:128 * channels + 3]
+    assert max(centre) > 0, "the centre of the frame shows the scene"
+    lit = sum(1 for row in rows for i in range(0, len(row), channels) if max(row[i:i + 3]) > 0)
+    assert lit > 0.5 * 256 * 256, "most of the frame is inside the box"
+    # the same program again with the same seed: the frame is reproducible bit for bit
+    out2 = str(tmp_path / "out" / "demo2.png")
+    r2 = subprocess.run([exe, out2], cwd=str(tmp_path), env=dict(os.environ, PATHTRACE_SEED="1234"), capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0 and open(out2, "rb").read() == open(out_png, "rb").read()

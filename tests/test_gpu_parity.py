@@ -611,3 +611,71 @@ def test_kernel_work_counters_exact_without_lights(oracle_lib):
         assert st["rays_traced"] == c["scene_queries"]
         assert 2 * st["node_visits"] + st["rays_traced"] == c["aabb_tests"]
         assert st["leaf_tests"] == c["tri_tests"] + c["sphere_tests"]
+
+
+def _lit_room(n_point_lights, emitters):
+    """A closed room with Lambertian, glass and mirror objects, `n_point_lights` PointLightSources and the given emissive geometry."""
+    sb = scenes.SceneBuilder()
+    sb.triangles(scenes.make_box((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), sb.material((0.75, 0.7, 0.65, 1.0)))
+    sb.sphere((0.35, -0.6, 0.1), 0.35, sb.material((1, 1, 1, 1), 1.5, bsdf=scenes.BSDF_GLASS))
+    sb.sphere((-0.45, -0.7, -0.3), 0.28, sb.material((0.9, 0.9, 1.0, 1), bsdf=scenes.BSDF_MIRROR))
+    rng = np.random.default_rng(31)
+    sb.triangles(rng.uniform(-0.8, 0.8, (300, 1, 3)).astype(np.float32) + rng.uniform(-0.1, 0.1, (300, 3, 3)).astype(np.float32), sb.material((0.4, 0.8, 0.5, 1.0)))
+    emitters(sb)
+    for k in range(n_point_lights):
+        a = 2.0 * np.pi * k / max(n_point_lights, 1)
+        sb.point_light((0.7 * np.cos(a), 0.3 + 0.05 * k, 0.7 * np.sin(a)), (0.2 + 0.05 * k, 0.3, 0.5 - 0.02 * k, 1.0))
+    return sb.build()
+
+
+def _three_emitters(sb):
+    sb.triangles(scenes.make_plane((-0.25, 0.97, -0.25), (0.25, 0.97, 0.25)), sb.material((1, 1, 1, 1), 1.0, (4, 3.5, 3, 1)), cull=True)
+    sb.sphere((-0.6, 0.4, 0.5), 0.1, sb.material((1, 1, 1, 1), 1.0, (1, 2, 4, 1)))
+
+
+def _emissive_mesh(sb):
+    """100,352 small emissive triangles: min(2 + int(log10(E + 1)), E) = 7 object samples per vertex (scene.cpp:226)"""
+    n = 224
+    xs, zs = np.meshgrid(np.linspace(-0.6, 0.6, n + 1, dtype=np.float32), np.linspace(-0.6, 0.6, n + 1, dtype=np.float32))
+    y = (np.float32(0.9) + np.float32(0.03) * np.sin(7 * xs) * np.cos(5 * zs)).astype(np.float32)
+    p = np.stack([xs, y, zs], axis=-1)
+    a, b, c, d = p[:-1, :-1], p[:-1, 1:], p[1:, :-1], p[1:, 1:]
+    tris = np.concatenate([np.stack([a, c, b], axis=2).reshape(-1, 3, 3), np.stack([b, c, d], axis=2).reshape(-1, 3, 3)])
+    sb.triangles(tris, sb.material((1, 1, 1, 1), 1.0, (2, 1.8, 1.5, 1)))
+
+
+@pytest.mark.parametrize("name,n_lights,emitters,expect_samples,w,h,mn,mx", [
+    ("12 point lights + 3 emitters", 12, _three_emitters, 14, 40, 40, 6, 6),
+    ("emissive mesh (k = 7) + 2 point lights", 2, _emissive_mesh, 9, 24, 24, 4, 4),
+    ("30 point lights + 3 emitters, adaptive", 30, _three_emitters, 32, 24, 24, 4, 12)])
+def test_many_light_samples_vs_oracle(oracle_lib, name, n_lights, emitters, expect_samples, w, h, mn, mx):
+    """Scene::sampleLights returns every LightSource and min(2 + int(log10(E + 1)), E) emitter samples per path vertex (scene.cpp:226,231-289)
+    with no upper bound; the device keeps a vertex's visibility bits in a 32-bit mask (round 2: 8).  Frames and engine states against the oracle."""
+    desc = _lit_room(n_lights, emitters)
+    cam = scenes.camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, -1.0)
+    for mode in ("host", "device"):
+        scene = _scene_with(mode, desc)
+        try:
+            n_emis = scene.info()["n_emissive"]
+            assert n_lights + min(2 + int(np.log10(n_emis + 1)), n_emis) == expect_samples
+            st, c = _pixel_job(scene, oracle_lib.scene_create(desc), cam, scenes.options(w, h, mn, mx))
+            assert st["shadow_rays_traced"] > 0 and st["samples"] == c["samples"]
+            ys, xs = np.mgrid[0:h:3, 0:w:3]
+            xs, ys = xs.ravel().astype(np.int32), ys.ravel().astype(np.int32)
+            states = np.arange(1, len(xs) + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+            opt = scenes.options(w, h, mn, mx)
+            img, after = scene.process_item(cam, opt, binding.pixel_streams(xs, ys, states))
+            want, want_after = oracle_lib.scene_create(desc).render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=8)
+            assert_bits_equal(img, want, name + ": streams")
+            assert_bits_equal(after, want_after, name + ": engine states")
+        finally:
+            scene.close()
+
+
+def test_more_than_32_light_samples_are_refused():
+    """The remaining limit (include/pt_hip.h): 33 samples per vertex do not fit the visibility mask; the scene is refused
+    when it is created, with a message that says why -- never rendered wrongly."""
+    desc = _lit_room(31, _three_emitters)  # 31 + 2
+    with pytest.raises(binding.PtError) as e:
+        binding.Scene(desc)
+    assert e.value.code == 4 and "more than 32 light samples" in str(e.value) and "31 point lights + 2 emitter samples" in str(e.value)

@@ -192,6 +192,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-weak-extra", action="store_true", help="N > 1, strong: skip the extra step of the weak-scaling frame")
     ap.add_argument("--size", type=int, default=1024, help="pixels per side: at one GPU (weak: sqrt(N) times as many at N GPUs) or of the fixed frame (strong)")
     ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--min-spp", type=int, default=0, help="min_sample_count (0 = --spp: the metric's fixed sample count); below --spp the per-pixel estimator may stop early "
+                    "(src/worker.cpp:239-259) and the value is on the max-spp basis, as the reference's benchmark counts items (benchmark/main.cpp:30)")
     ap.add_argument("--mesh-n", type=int, default=1900, help="stand-in mesh resolution (nu = nv); 1900 -> 7.2 M triangles")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
@@ -315,14 +317,14 @@ def run_rank(args):
     scene = None
     if standin:
         from cpupathtrace_amd import scenes
-        opt = scenes.options(width, height, args.spp, args.spp)
+        opt = scenes.options(width, height, args.min_spp or args.spp, args.spp)
         sc, cam, label, gen_s, create_s, info = {"obj_kind": []}, None, "stand-in renderer (test only)", 0.0, 0.0, {"depth": 0}
         job = sharding.ShardedJob(None, None, opt, rank, world, device, base_seed=base_seed, render_fn=standin_render_fn(width, base_seed))
     else:
         from cpupathtrace_amd import binding, scenes
         with heartbeat("generating the scene"):
             sc, cam, label, gen_s = build_workload(args.workload, width, height, args.mesh_n)
-        opt = scenes.options(width, height, args.spp, args.spp)
+        opt = scenes.options(width, height, args.min_spp or args.spp, args.spp)
         t0 = time.time()
         with heartbeat("building the BVH and uploading the scene"):
             scene = binding.Scene(sc, device=dev_index)
@@ -358,7 +360,7 @@ def run_rank(args):
     if world > 1 and args.scaling == "strong" and not args.no_weak_extra:
         w2, h2 = frame_for(world, args.size, "weak")
         from cpupathtrace_amd import scenes as _scenes
-        opt2 = _scenes.options(w2, h2, args.spp, args.spp)
+        opt2 = _scenes.options(w2, h2, args.min_spp or args.spp, args.spp)
         if standin:
             job2 = sharding.ShardedJob(None, None, opt2, rank, world, device, base_seed=base_seed, render_fn=standin_render_fn(w2, base_seed))
         else:
@@ -391,7 +393,9 @@ def run_rank(args):
             "metric": "Msamples/s (all bounces)" if not standin else "INVALID (stand-in renderer, test only)", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not standin else "stand-in renderer (test only)",
-            "config": {"workload": "%s, %dx%d, %d spp (min = max), per-pixel engines seeded from base seed %d" % (label, width, height, args.spp, args.seed),
+            "config": {"workload": "%s, %dx%d, %s, per-pixel engines seeded from base seed %d" % (
+                label, width, height, ("%d spp (min = max)" % args.spp) if not args.min_spp or args.min_spp == args.spp else
+                ("%d..%d spp (adaptive: value on the max-spp basis)" % (args.min_spp, args.spp)), args.seed),
                        "objects": int(len(sc["obj_kind"])), "bvh_depth": int(info["depth"]), "tiles_per_gpu": int(job.n_local_tiles),
                        "tiles_total": int(len(job.tiles)),
                        "parallelism": ("one GPU: one persistent launch per frame, no gather" if world == 1 else
@@ -401,6 +405,10 @@ def run_rank(args):
             "distributed": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else "none"),
                             "gather_bytes_per_step": int(job.gather_bytes), "ranks": per_rank},
         }
+        if stats is not None and args.min_spp and args.min_spp != args.spp:
+            drawn = sum(int(r["samples"]) for r in per_rank)
+            out["adaptive"] = {"samples_drawn_last_step": drawn, "fraction_of_max": drawn / (float(width) * height * args.spp),
+                               "msamples_drawn_per_s": drawn / (elapsed / args.steps) / 1e6}
         if weak is not None:
             out["weak"] = weak
         if stats is not None:

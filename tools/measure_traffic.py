@@ -10,7 +10,7 @@ line misses L2 87 % of the time)."""
 import csv, glob, json, sys
 
 key, fetch_dir, write_dir, out = sys.argv[1:5]
-samples = float(sys.argv[5]) if len(sys.argv) > 5 else 64.0 * 1024 * 1024  # samples of the profiled frame (bench.py --spp 64)
+samples = float(sys.argv[5]) if len(sys.argv) > 5 else 64.0 * 1024 * 1024  # samples of the profiled frame (width * height * spp)
 
 
 def per_launch(root, counter):
@@ -28,7 +28,8 @@ write_kib, n2 = per_launch(write_dir, "WRITE_SIZE")
 entry = {"kernel": "pt_path_kernel", "fetch_size_kib_per_launch": fetch_kib, "write_size_kib_per_launch": write_kib, "launches": n1,
          "bytes_per_launch": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0,
          "bytes_per_sample": (2.0 * fetch_kib * 1024.0 + write_kib * 1024.0) * n1 / samples,
-         "note": "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 64 B per 128-B request), separate rocprofv3 --pmc passes over one frame of the same workload (tools/pmc2.sh + tools/render_once.py); one launch per frame"}
+         "samples_per_launch": samples,
+         "note": "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 64 B per 128-B request), separate rocprofv3 --pmc passes over one step of bench.py on the same workload (tools/traffic_pass.sh); one launch per frame"}
 try:
     data = json.load(open(out))
 except (OSError, ValueError):

@@ -7,6 +7,7 @@ i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
+  case " ${PMC_SKIP:-} " in *" $i "*) continue;; esac
   timeout -k 5 ${PMC_TIMEOUT:-150} rocprofv3 --pmc $group --output-format csv -d "$out/pass$i" -- "$@" > "$out/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$out/pass$i.log"; }
   echo "pass $i done: $group"
 done <<'GROUPS'

@@ -292,11 +292,11 @@ int setup_path(pt_scene *s) {
     }
     cfg.in_lds = (s->dev.n_lds_pairs == s->dev.n_pairs && s->dev.n_lds_tris == s->dev.n_tris && s->dev.n_lds_pairs + s->dev.n_lds_tris > 0) ? 1 : 0;
     // 8 stack entries per lane in LDS (16 KB per workgroup) let four workgroups share a CU; deeper walks use the HBM spill area
-    int stack_lds = env_int("PT_STACK_LDS", 8);
-    cfg.stack_lds = stack_lds == 8 ? 8 : 16;
+    cfg.stack_lds = 8;
+    cfg.wide = s->dev.n_lights + s->dev.n_object_samples > 8U ? 1 : 0;
     cfg.rows = std::min(std::max(env_int("PT_ROWS", 4), 1), PT_MAX_ROWS);
-    cfg.lds_bytes = pt_path_lds_bytes(cfg.stack_lds, cfg.rows, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.pair_base : 0U);
-    const int per_cu = pt_path_blocks_per_cu(cfg.stack_lds, cfg.in_lds, cfg.lds_bytes);
+    cfg.lds_bytes = pt_path_lds_bytes(cfg.wide, cfg.rows, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.pair_base : 0U);
+    const int per_cu = pt_path_blocks_per_cu(cfg.wide, cfg.in_lds, cfg.lds_bytes);
     const int limit = env_int("PT_BLOCKS_PER_CU", 0);
     s->path_blocks_per_cu = (limit > 0 && limit < per_cu) ? limit : per_cu;
     // a walk's stack holds at most one parked node per level of the tree and the sentinel at its bottom (pt_path.hip); what does not fit the LDS window spills
@@ -305,7 +305,9 @@ int setup_path(pt_scene *s) {
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
     cfg.ready_shift = std::min(std::max(env_int("PT_READY_SHIFT", 1), 0), 31);
     cfg.prefetch = env_int("PT_PREFETCH", 0) != 0 ? 1 : 0;
-    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", 12), 1), 64);
+    // steps between two looks at the ring.  Trees in HBM: 8 -> 397, 12 -> 407, 16 -> 412, 24 -> 422, 32 -> 421 Msamples/s (round 3 made the step
+    // cheaper, looking at the ring costs what it did); scenes in LDS keep 12 (Cornell: 700 against 659 with 24)
+    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", cfg.in_lds ? 12 : 24), 1), 64);
     cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 8), 1), 64); // lanes that wait for the rare step before it runs: 2 -> 374, 4 -> 396, 8 -> 414, 12 -> 415, 16 -> 414 Msamples/s
     if(env_int("PT_DEBUG", 0) != 0) {
         std::fprintf(stderr, "[pt] path kernel: %d CUs x %d workgroups, %d rows of slots per wavefront, stack_lds %d, scene %s, lds %zu B, spill depth %u\n", s->cu_count,

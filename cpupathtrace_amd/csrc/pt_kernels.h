@@ -85,6 +85,7 @@ struct PtPathConfig {
     int grid;             // workgroups of 256 threads
     int rows;             // rows of 64 slots per wavefront (<= PT_MAX_ROWS)
     int slots_per_wave;   // slots a wavefront really uses (<= rows * 64; fewer for small jobs)
+    int wide;             // more than 8 light samples per path vertex: the slots use the 64-bit word (pt_path.hip, SlotWord)
     int stack_lds;        // traversal stack entries per lane kept in LDS
     uint32_t spill_depth; // further entries per lane in HBM
     uint2 *spill;
@@ -124,8 +125,8 @@ struct PtPathArgs {
 // fills *host_args (which must stay valid until the launch has been issued), copies it to d_args on `stream` and launches
 void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams,
                     PtLocalQueue queue, const PtPathConfig &cfg, float4 *image, PtDevCounters *counters, PtPathArgs *host_args, PtPathArgs *d_args);
-int pt_path_blocks_per_cu(int stack_lds, int in_lds, size_t lds_bytes);
-size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records); // leaf records: triangles + 1 spare + spheres, 0 = scene not in LDS
+int pt_path_blocks_per_cu(int wide, int in_lds, size_t lds_bytes);
+size_t pt_path_lds_bytes(int wide, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records); // leaf records: triangles + 1 spare + spheres, 0 = scene not in LDS
 // Scene::getIntersection for n rays (6 floats each): out[i] = (bits t, ref)
 // diagnostic (tools/replay_probe.py): the traversal alone over the rays a render left in its rings; returns the resident workgroups per CU
 int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueue &Q, uint32_t n_logs, uint32_t parts, int waves_per_simd, const PtPathConfig &cfg,

@@ -393,20 +393,43 @@ struct Tracer {
     }
 };
 
-// ---- the per-slot word in LDS (64 bits) --------------------------------------------------------------------------------------------------
-// bits 0..31  visibility of the last vertex's light samples (1 = unoccluded), set by the lanes that finish the shadow rays
-// bits 32..39 rays of the slot still in the queue or being walked
-// bits 40..47 PT_F_* flags of the slot
-// A lane that finishes a shadow ray adds (visibility bit) - (one ray) with ONE 64-bit LDS atomic.  Which light samples of the last vertex
-// have a contribution waiting in S.nee is kept with the slot's state in HBM (S.nee_mask): only the shading pass needs it.
-// Scene::sampleLights has no upper bound on the samples per vertex (every LightSource + min(2 + log10(E + 1), E) emitters, scene.cpp:226,231);
-// the 32 bits of the visibility mask are this kernel's (PT_MAX_NEE).
-typedef unsigned long long __attribute__((address_space(3))) *lds_u64_ptr;
-#define PT_W_VIS(word) ((uint32_t)(word))
-#define PT_W_PENDING(word) ((uint32_t)((word) >> 32) & 0xffu)
-#define PT_W_FLAGS(word) ((uint32_t)((word) >> 40) & 0xffu)
-#define PT_W_ONE_RAY (1ULL << 32)
-#define PT_W_MAKE(flags, rays, vis) (((unsigned long long)(flags) << 40) | ((unsigned long long)(rays) << 32) | (unsigned long long)(vis))
+// ---- the per-slot word in LDS -----------------------------------------------------------------------------------------------------------
+// What the lanes that finish a slot's rays and the shading pass tell each other:
+//   visibility of the last vertex's light samples (1 = unoccluded), set by the lanes that finish the shadow rays;
+//   rays of the slot still in the queue or being walked;  PT_F_* flags of the slot.
+// A lane that finishes a shadow ray adds (visibility bit) - (one ray) with ONE LDS atomic.
+// Scene::sampleLights has no upper bound on the samples per vertex (every LightSource + min(2 + log10(E + 1), E) emitters, scene.cpp:226,231).
+// Scenes with at most 8 of them -- every scene of the reference's programs -- use a 32-bit word that also holds which samples have a
+// contribution waiting in S.nee (COMPACT: bits 0-7 visibility, 8-15 rays, 16-23 flags, 24-31 waiting); scenes with up to PT_MAX_NEE = 32
+// use a 64-bit word (WIDE: bits 0-31 visibility, 32-39 rays, 40-47 flags) and keep the waiting mask with the slot's state in HBM
+// (S.nee_mask: only the shading pass needs it).  The wide form costs the benchmark scene 5 % (one more load and store per slot and pass,
+// 64-bit LDS traffic), which is why the compact one stays.
+template<bool WIDE>
+struct SlotWord {
+    typedef uint32_t T;
+    typedef uint32_t __attribute__((address_space(3))) *lds_ptr;
+    static constexpr uint32_t j_mask = 7u;
+    static PT_D uint32_t vis(T w) { return w & 0xffu; }
+    static PT_D uint32_t pending(T w) { return (w >> 8) & 0xffu; }
+    static PT_D uint32_t flags(T w) { return (w >> 16) & 0xffu; }
+    static PT_D T one_ray() { return 0x100u; }
+    static PT_D T make(uint32_t flags, uint32_t rays, uint32_t vis, uint32_t waiting) { return (waiting << 24) | (flags << 16) | (rays << 8) | vis; }
+    static PT_D uint32_t waiting(T w, const PtSlots &, size_t) { return w >> 24; }
+    static PT_D void keep_waiting(const PtSlots &, size_t, uint32_t) {}
+};
+template<>
+struct SlotWord<true> {
+    typedef unsigned long long T;
+    typedef unsigned long long __attribute__((address_space(3))) *lds_ptr;
+    static constexpr uint32_t j_mask = 31u;
+    static PT_D uint32_t vis(T w) { return (uint32_t)w; }
+    static PT_D uint32_t pending(T w) { return (uint32_t)(w >> 32) & 0xffu; }
+    static PT_D uint32_t flags(T w) { return (uint32_t)(w >> 40) & 0xffu; }
+    static PT_D T one_ray() { return 1ULL << 32; }
+    static PT_D T make(uint32_t flags, uint32_t rays, uint32_t vis, uint32_t) { return ((T)flags << 40) | ((T)rays << 32) | (T)vis; }
+    static PT_D uint32_t waiting(T, const PtSlots &S, size_t p) { return S.nee_mask[p]; }
+    static PT_D void keep_waiting(const PtSlots &S, size_t p, uint32_t mask) { S.nee_mask[p] = mask; }
+};
 
 #define PT_DEST_SLOT_MASK 0xffffu
 #define PT_DEST_J_SHIFT 16
@@ -473,17 +496,19 @@ struct ShadeTables {
 // and every draw of a vertex (roulette, lights, BSDF) is made by the single invocation that shades the vertex.
 // New rays go to the wave's ring: extension rays first, then the shadow rays light sample by light sample (ballot + prefix popcount
 // give every lane its position; rays of one kind from neighbouring pixels end up in neighbouring lanes of the traversal).
+template<bool WIDE>
 PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOptions &opt, const PtSlots &S, const PtStreams &T, const PtLocalQueue &Q,
-                    WaveCtx &ctx, uint32_t row, uint32_t lane, size_t slot_base, size_t queue_base, lds_u64_ptr word_l, lds_u2_ptr hit_l,
+                    WaveCtx &ctx, uint32_t row, uint32_t lane, size_t slot_base, size_t queue_base, typename SlotWord<WIDE>::lds_ptr word_l, lds_u2_ptr hit_l,
                     float4 *__restrict__ image, PtDevCounters *counters, const ShadeTables &tb, uint32_t &n_samples, uint32_t &n_vertices) {
     const uint32_t ls = row * 64 + lane; // slot of the wave
     const size_t p = slot_base + ls;     // slot of the grid
     const unsigned long long lt = (1ULL << lane) - 1ULL;
     const uint32_t n_light_samples = sc.n_lights + sc.n_object_samples;
-    const unsigned long long word = word_l[ls];
-    uint32_t flags = PT_W_FLAGS(word);
-    const uint32_t vis_bits = PT_W_VIS(word);
-    bool ready = !(flags & PT_F_DONE) && PT_W_PENDING(word) == 0;
+    typedef SlotWord<WIDE> SW;
+    const typename SW::T word = word_l[ls];
+    uint32_t flags = SW::flags(word);
+    const uint32_t vis_bits = SW::vis(word);
+    bool ready = !(flags & PT_F_DONE) && SW::pending(word) == 0;
     if(__ballot(ready) == 0ULL) {
         return;
     }
@@ -555,7 +580,7 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
             else if(want) {
                 flags = PT_F_DONE;
                 ready = false;
-                word_l[ls] = PT_W_MAKE(PT_F_DONE, 0u, 0u);
+                word_l[ls] = SW::make(PT_F_DONE, 0u, 0u, 0u);
             }
             ctx.n_dead += (uint32_t)__popcll(__ballot(want && !got));
         }
@@ -586,7 +611,7 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
             // state, and -- a single word, to bring the line into the caches -- the shading record of the triangle that was hit, which
             // is the one access of this pass that usually comes from HBM.
             const float4 out4 = S.out[p];
-            uint32_t mask = S.nee_mask[p];
+            uint32_t mask = SW::waiting(word, S, p);
             // the first two light samples (most scenes have no more) are fetched with the batch, the others one by one below
             const uint32_t lit = mask & vis_bits;
             float4 nee0 = make_float4(0, 0, 0, 0), nee1 = make_float4(0, 0, 0, 0);
@@ -928,8 +953,8 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
         n_rays++;
     }
     if(alive) {
-        word_l[ls] = PT_W_MAKE(flags, n_rays, vis_init);
-        S.nee_mask[p] = nee_out_mask;
+        word_l[ls] = SW::make(flags, n_rays, vis_init, nee_out_mask);
+        SW::keep_waiting(S, p, nee_out_mask);
         S.rng[p] = rng;
         S.cursor[p] = cursor;
         if(flags & PT_F_IN_FLIGHT) {
@@ -946,12 +971,15 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
 
 // ---- the kernel -------------------------------------------------------------------------------------------------------------------------
 
+#define PT_PATH_STACK_LDS 8 /* entries of a lane's traversal stack kept in LDS (16 KB per workgroup: four workgroups share a CU); deeper ones spill to HBM */
 #ifndef PT_PATH_WAVES
 #define PT_PATH_WAVES 4 /* 128 VGPRs: the traversal loop has no spills there; three waves per SIMD hide less of the node-fetch latency (profiles/) */
 #endif
 
-template<int STACK_LDS, bool IN_LDS>
+template<bool WIDE, bool IN_LDS>
 __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPathArgs *__restrict__ args) {
+    constexpr int STACK_LDS = PT_PATH_STACK_LDS;
+    typedef SlotWord<WIDE> SW;
     // The argument block is read-only for the whole launch: it is addressed as CONSTANT memory (scalar loads; and pointers loaded from
     // constant memory are known to be global ones, so everything reached through them stays global_load / global_store).
     const args_c4 A4 = (args_c4)args;
@@ -979,8 +1007,8 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     at += (size_t)STACK_LDS * 256 * sizeof(uint2);
     lds_u2_ptr hit_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(at) + wave_in_block * n_slots;
     at += (size_t)4 * n_slots * sizeof(uint2);
-    lds_u64_ptr word_l = (lds_u64_ptr)reinterpret_cast<unsigned long long *>(at) + wave_in_block * n_slots;
-    at += (size_t)4 * n_slots * sizeof(unsigned long long);
+    typename SW::lds_ptr word_l = (typename SW::lds_ptr)reinterpret_cast<typename SW::T *>(at) + wave_in_block * n_slots;
+    at += (size_t)4 * n_slots * sizeof(typename SW::T);
     float *cdf_l = reinterpret_cast<float *>(at);
     at += (size_t)PT_LDS_TABLE_MAX * sizeof(float);
     float4 *emis_l = reinterpret_cast<float4 *>(at);
@@ -1032,7 +1060,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     for(uint32_t i = lane; i < n_slots; i += 64) {
         // no stream, nothing pending: ready to take a stream.  (A small job uses only the first slots of every wavefront: its streams are
         // spread over all the wavefronts the chip holds, because a stream's samples are sequential and only more wavefronts shorten the chain.)
-        word_l[i] = i < (uint32_t)slots_per_wave ? 0ULL : PT_W_MAKE(PT_F_DONE, 0u, 0u);
+        word_l[i] = i < (uint32_t)slots_per_wave ? (typename SW::T)0 : SW::make(PT_F_DONE, 0u, 0u, 0u);
     }
     __syncthreads(); // the only barrier: from here on the four wavefronts of the workgroup never wait for each other
 
@@ -1124,7 +1152,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
             }
 #pragma unroll 1
             for(uint32_t r = 0; r < (uint32_t)rows; r++) {
-                shade_row(P->sc, P->cam, P->opt, P->S, P->T, P->Q, ctx, r, lane, slot_base, queue_base, word_l, hit_l, P->image, P->counters, tb, n_samples, n_vertices);
+                shade_row<WIDE>(P->sc, P->cam, P->opt, P->S, P->T, P->Q, ctx, r, lane, slot_base, queue_base, word_l, hit_l, P->image, P->counters, tb, n_samples, n_vertices);
             }
             // the rays just written are read back by other lanes of this wavefront
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1175,14 +1203,14 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
             if(active && w.cur == PT_REF_NONE) {
                 const uint32_t ls = w.dest & PT_DEST_SLOT_MASK;
                 if(w.dest & PT_DEST_SHADOW) {
-                    const uint32_t j = (w.dest >> PT_DEST_J_SHIFT) & 31u;
+                    const uint32_t j = (w.dest >> PT_DEST_J_SHIFT) & SW::j_mask;
                     // one ray less pending; an unoccluded light sample sets its visibility bit
-                    __hip_atomic_fetch_add(&word_l[ls], (unsigned long long)(w.occluded ? 0u : (1u << j)) - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&word_l[ls], (typename SW::T)(w.occluded ? 0u : (1u << j)) - SW::one_ray(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 else {
                     const u2v h = {__float_as_uint(w.best_ref == PT_REF_NONE ? -1.0f : w.best_t), w.best_ref};
                     hit_l[ls] = h;
-                    __hip_atomic_fetch_add(&word_l[ls], 0ULL - PT_W_ONE_RAY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&word_l[ls], (typename SW::T)0 - SW::one_ray(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 active = false;
             }
@@ -1195,8 +1223,8 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                     // slots whose rays have all come back (or that wait for a stream)
                     uint32_t n_ready = 0;
                     for(uint32_t r = 0; r < (uint32_t)rows; r++) {
-                        const unsigned long long word = word_l[r * 64 + lane];
-                        n_ready += (uint32_t)__popcll(__ballot(!(PT_W_FLAGS(word) & PT_F_DONE) && PT_W_PENDING(word) == 0));
+                        const typename SW::T word = word_l[r * 64 + lane];
+                        n_ready += (uint32_t)__popcll(__ballot(!(SW::flags(word) & PT_F_DONE) && SW::pending(word) == 0));
                     }
                     // enough of them for a pass: `min_ready`, or a share of the slots that are still alive -- a wavefront that is down to its
                     // last few streams must not make each of them wait for all the others (their samples are sequential: the launch lasts as
@@ -1524,15 +1552,15 @@ int launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueu
     return blocks;
 }
 
-template<int STACK_LDS, bool IN_LDS>
+template<bool WIDE, bool IN_LDS>
 void launch_path(hipStream_t stream, const PtPathConfig &cfg, const PtPathArgs *d_args) {
-    hipLaunchKernelGGL((pt_path_kernel<STACK_LDS, IN_LDS>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, d_args);
+    hipLaunchKernelGGL((pt_path_kernel<WIDE, IN_LDS>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, d_args);
 }
 
-template<int STACK_LDS, bool IN_LDS>
+template<bool WIDE, bool IN_LDS>
 int occupancy(size_t lds_bytes) {
     int blocks = 0;
-    const hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_path_kernel<STACK_LDS, IN_LDS>, 256, lds_bytes);
+    const hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_path_kernel<WIDE, IN_LDS>, 256, lds_bytes);
     return (err != hipSuccess || blocks < 1) ? 1 : blocks;
 }
 
@@ -1544,22 +1572,22 @@ void launch_closest(hipStream_t stream, const PtDevScene &scene, const float *ra
 
 } // namespace
 
-#define PT_DISPATCH(fn, cfg, ...)                                  \
+#define PT_DISPATCH_PATH(fn, cfg, ...)                             \
     do {                                                           \
         if((cfg).in_lds) {                                         \
-            if((cfg).stack_lds == 8) {                             \
-                fn<8, true>(__VA_ARGS__);                          \
+            if((cfg).wide) {                                       \
+                fn<true, true>(__VA_ARGS__);                       \
             }                                                      \
             else {                                                 \
-                fn<16, true>(__VA_ARGS__);                         \
+                fn<false, true>(__VA_ARGS__);                      \
             }                                                      \
         }                                                          \
         else {                                                     \
-            if((cfg).stack_lds == 8) {                             \
-                fn<8, false>(__VA_ARGS__);                         \
+            if((cfg).wide) {                                       \
+                fn<true, false>(__VA_ARGS__);                      \
             }                                                      \
             else {                                                 \
-                fn<16, false>(__VA_ARGS__);                        \
+                fn<false, false>(__VA_ARGS__);                     \
             }                                                      \
         }                                                          \
     } while(0)
@@ -1589,7 +1617,7 @@ void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCame
     a.counters = counters;
     a.wave_counters = cfg.wave_counters;
     (void)hipMemcpyAsync(d_args, host_args, sizeof(PtPathArgs), hipMemcpyHostToDevice, stream);
-    PT_DISPATCH(launch_path, cfg, stream, cfg, d_args);
+    PT_DISPATCH_PATH(launch_path, cfg, stream, cfg, d_args);
 }
 
 void pt_launch_steptime(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint32_t lanes_per_wave, uint4 *out, uint2 *spill, uint32_t spill_depth, int prefetch) {
@@ -1606,7 +1634,12 @@ void pt_launch_closest(hipStream_t stream, const PtDevScene &scene, const float 
     if(n == 0) {
         return;
     }
-    PT_DISPATCH(launch_closest, cfg, stream, scene, rays6, n, out, cfg);
+    if(cfg.in_lds) {
+        launch_closest<PT_PATH_STACK_LDS, true>(stream, scene, rays6, n, out, cfg);
+    }
+    else {
+        launch_closest<PT_PATH_STACK_LDS, false>(stream, scene, rays6, n, out, cfg);
+    }
 }
 
 int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueue &Q, uint32_t n_logs, uint32_t parts, int waves_per_simd, const PtPathConfig &cfg,
@@ -1620,14 +1653,14 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
     }
 }
 
-size_t pt_path_lds_bytes(int stack_lds, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
+size_t pt_path_lds_bytes(int wide, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
     const size_t scene = ((size_t)n_lds_pairs + n_lds_leaf_records) * 64;
-    return (size_t)stack_lds * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + sizeof(unsigned long long)) + PT_LDS_TABLE_BYTES + scene;
+    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t))) + PT_LDS_TABLE_BYTES + scene;
 }
 
-int pt_path_blocks_per_cu(int stack_lds, int in_lds, size_t lds_bytes) {
+int pt_path_blocks_per_cu(int wide, int in_lds, size_t lds_bytes) {
     if(in_lds) {
-        return stack_lds == 8 ? occupancy<8, true>(lds_bytes) : occupancy<16, true>(lds_bytes);
+        return wide ? occupancy<true, true>(lds_bytes) : occupancy<false, true>(lds_bytes);
     }
-    return stack_lds == 8 ? occupancy<8, false>(lds_bytes) : occupancy<16, false>(lds_bytes);
+    return wide ? occupancy<true, false>(lds_bytes) : occupancy<false, false>(lds_bytes);
 }

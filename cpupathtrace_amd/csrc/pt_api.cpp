@@ -305,10 +305,9 @@ int setup_path(pt_scene *s) {
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
     cfg.ready_shift = std::min(std::max(env_int("PT_READY_SHIFT", 1), 0), 31);
     cfg.prefetch = env_int("PT_PREFETCH", 0) != 0 ? 1 : 0;
-    // steps between two looks at the ring.  Trees in HBM: 8 -> 397, 12 -> 407, 16 -> 412, 24 -> 422, 32 -> 421 Msamples/s (round 3 made the step
-    // cheaper, looking at the ring costs what it did); scenes in LDS keep 12 (Cornell: 700 against 659 with 24)
-    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", cfg.in_lds ? 12 : 24), 1), 64);
-    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", 8), 1), 64); // lanes that wait for the rare step before it runs: 2 -> 374, 4 -> 396, 8 -> 414, 12 -> 415, 16 -> 414 Msamples/s
+    // (burst_steps and leaf_min depend on the job's size as well: ensure_path_workspace sets them per job and keeps the last job's here)
+    cfg.burst_steps = 24;
+    cfg.leaf_min = 8;
     if(env_int("PT_DEBUG", 0) != 0) {
         std::fprintf(stderr, "[pt] path kernel: %d CUs x %d workgroups, %d rows of slots per wavefront, stack_lds %d, scene %s, lds %zu B, spill depth %u\n", s->cu_count,
                      s->path_blocks_per_cu, cfg.rows, cfg.stack_lds, cfg.in_lds ? "in LDS" : "in HBM", cfg.lds_bytes, cfg.spill_depth);
@@ -356,6 +355,13 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
         }
     }
     cfg.first_lanes = static_cast<int>(first_lanes);
+    // Steps between two looks at the ring.  Trees in HBM: 8 -> 397, 12 -> 407, 16 -> 412, 24 -> 422, 32 -> 421 Msamples/s on the benchmark frame
+    // (round 3 made the step cheaper, looking at the ring costs what it did); scenes in LDS keep 12 on a full grid (Cornell: 700 against 659
+    // with 24) and take 24 when a wavefront has less than a row of slots (the reference's benchmark program, 128 x 128: 136 -> 176 Msamples/s).
+    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", (cfg.in_lds && slots_per_wave >= 64U) ? 12 : 24), 1), 64);
+    // Lanes that wait for the rare step (leaves) before it runs: 2 -> 374, 4 -> 396, 8 -> 414, 12 -> 415 Msamples/s on the benchmark frame; a
+    // wavefront with 16 slots cannot wait for 8 of them (128 x 128, 180 k triangles: 8 -> 54, 4 -> 59, 2 -> 62 Msamples/s)
+    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", cfg.in_lds ? 8 : static_cast<int>(std::min<uint32_t>(std::max<uint32_t>(slots_per_wave / 8U, 2U), 8U))), 1), 64);
     const uint32_t rows = (slots_per_wave + 63U) / 64U;
     const uint32_t total = waves * rows * 64U;
     const uint32_t rays_per_slot = 1U + s->dev.n_lights + s->dev.n_object_samples;
@@ -398,6 +404,8 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     s->path_slots = total;
     s->path_waves = waves;
     s->path_cap = cap;
+    s->path_cfg.burst_steps = cfg.burst_steps; // (the diagnostics that follow a render -- pt_debug_replay_rays -- run with its settings)
+    s->path_cfg.leaf_min = cfg.leaf_min;
     *out_cfg = cfg;
     return PT_OK;
 }

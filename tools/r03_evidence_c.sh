@@ -4,6 +4,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r03; mkdir -p $out
 export PYTHONUNBUFFERED=1
 case "$1" in
+ benches)
+  timeout -k 10 200 python3 bench.py --workload box --spp 256 --cpu-seconds 0 > $out/box_spp256.json 2> $out/box.log
+  timeout -k 10 200 python3 bench.py --workload cornell --spp 256 --cpu-seconds 0 > $out/cornell_spp256.json 2> $out/cornell.log
+  timeout -k 10 300 python3 bench.py --workload dragon --size 2048 --spp 256 --cpu-seconds 0 > $out/dragon_size2048_spp256.json 2> $out/dragon2048.log
+  ;;
  small)
   tools/traffic_pass.sh box 0 1024 256 $out && timeout -k 10 200 python3 bench.py --workload box --spp 256 --cpu-seconds 0 > $out/box_spp256.json 2> $out/box.log
   tools/traffic_pass.sh cornell 0 1024 256 $out && timeout -k 10 200 python3 bench.py --workload cornell --spp 256 --cpu-seconds 0 > $out/cornell_spp256.json 2> $out/cornell.log

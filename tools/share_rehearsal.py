@@ -2,8 +2,8 @@
 
     python tools/share_rehearsal.py [--workload dragon] [--mesh-n 1900] [--size 1024] [--spp 1024] [--n 1,2,4,8] [--env "{...}" ...]
 
-bench.py --gpus N gives rank R the tiles `tiles[R::N]` of processJob's tile list (cpupathtrace_amd/sharding.py; the reference's tile queue,
-src/worker.cpp:398-414, dealt round-robin).  The ranks share nothing while they render, so rank R's time on its own GPU is the time this
+bench.py --gpus N gives rank R every N-th tile of processJob's tile list (cpupathtrace_amd/sharding.py `local_tiles`: the reference's tile
+queue, src/worker.cpp:398-414, dealt round-robin along the diagonals of the tile grid).  The ranks share nothing while they render, so rank R's time on its own GPU is the time this
 GPU needs for that tile set alone; the frame is finished when the slowest rank is (the gather is 16 MB / N per rank, tens of microseconds
 over xGMI).  Predicted speed-up of N GPUs = T(all tiles) / max_R T(tiles[R::N]).  Times are wall seconds of the render call with the
 output in device memory (what bench.py times) and the launch duration by HIP events beside them.
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=1)
     args = ap.parse_args()
     import torch
-    from cpupathtrace_amd import binding, scenes
+    from cpupathtrace_amd import binding, scenes, sharding
     import bench
 
     sc, cam, label, gen_s = bench.build_workload(args.workload, args.size, args.size, args.mesh_n)
@@ -55,7 +55,7 @@ def main():
                 ranks = sorted(set(int(round(i * (n - 1) / max(int(args.ranks) - 1, 1))) for i in range(int(args.ranks))))
             worst = 0.0
             for r in ranks:
-                mine = tiles[r::n]
+                mine = sharding.local_tiles(tiles, r, n)
                 pixels = int((mine["w"].astype(np.int64) * mine["h"]).sum())
                 scene.process_job_device(cam, scenes.options(args.size, args.size, 2, 2), image.data_ptr(), stream, tiles=mine)  # workspace for this job size
                 torch.cuda.synchronize()

@@ -11,3 +11,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/measure_traffic.py $key $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/traffic.json $(python3 -c "print($size * $size * $spp)")
 rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+# (bench.py looks its traffic figures up under profiles/)
+python3 - $out/traffic.json profiles/r03_traffic.json <<'PY'
+import json, sys
+try:
+    data = json.load(open(sys.argv[2]))
+except (OSError, ValueError):
+    data = {}
+data.update(json.load(open(sys.argv[1])))
+json.dump(data, open(sys.argv[2], "w"), indent=1)
+PY

@@ -184,6 +184,11 @@ struct pt_scene {
     uint32_t *host_tiles_done = nullptr; // pinned: tiles finished so far, written by the kernel (progress callback)
     unsigned long long *host_streams_done = nullptr; // pinned: the launch's count of finished streams, copied behind every launch
     uint64_t streams_expected = 0;                   // ... and what it must read once the stream has drained (finish_path)
+    // cost-aware placement (render_tiles_impl): what every stream of the pilot launch cost, and the stream every slot of the main launch starts with
+    DevBuf<uint32_t> sl_cost, stream_cost, place;
+    bool debug_collect_costs = false;                // pt_debug_collect_costs: every launch records them
+    std::vector<uint32_t> debug_place;               // pt_debug_set_place: the next launch starts from this table ...
+    uint32_t debug_place_waves = 0, debug_place_slots = 0; // ... with this many wavefronts and slots in each
 
     ~pt_scene() {
         if(host_tiles_done != nullptr) {
@@ -315,8 +320,15 @@ int setup_path(pt_scene *s) {
     return PT_OK;
 }
 
+// A first round chosen by the host instead of the kernel's arithmetic: `waves` wavefronts (a multiple of 4) with `slots_per_wave` slots each,
+// slot q of wavefront w starting with stream place[w * slots_per_wave + q] (device memory; 0xffffffff = the slot stays empty).
+struct PathPlan {
+    uint32_t waves = 0, slots_per_wave = 0;
+    const uint32_t *d_place = nullptr;
+};
+
 // Grid and slot rows for n streams, and the buffers they need.
-int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
+int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg, const PathPlan *plan = nullptr) {
     int rc = setup_path(s);
     if(rc != PT_OK) {
         return rc;
@@ -331,9 +343,18 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     if(waves_wanted < spread) {
         waves_wanted = std::min<uint32_t>(spread, n);              // thin rows
     }
-    const uint32_t grid = std::max<uint32_t>(1U, std::min<uint32_t>(max_grid, (waves_wanted + 3U) / 4U));
+    uint32_t grid = std::max<uint32_t>(1U, std::min<uint32_t>(max_grid, (waves_wanted + 3U) / 4U));
+    if(plan != nullptr) {
+        grid = std::max<uint32_t>(1U, std::min<uint32_t>(max_grid, plan->waves / 4U));
+    }
     const uint32_t waves = grid * 4U;
     uint32_t slots_per_wave = std::min<uint32_t>(static_cast<uint32_t>(cfg.rows) * 64U, std::max<uint32_t>(1U, (n + waves - 1U) / waves));
+    if(plan != nullptr) {
+        if(waves != plan->waves || plan->slots_per_wave == 0 || plan->slots_per_wave > static_cast<uint32_t>(cfg.rows) * 64U) {
+            return fail(PT_ERR_INVALID, "placement: " + std::to_string(plan->waves) + " wavefronts x " + std::to_string(plan->slots_per_wave) + " slots do not fit this device");
+        }
+        slots_per_wave = plan->slots_per_wave;
+    }
     // The first round of streams goes to the slots in pieces of `first_lanes` neighbouring slots (pt_path.hip, stream hand-out): a
     // wavefront's slots are a whole number of pieces (a large job gets up to 7 more slots per wavefront, a small one pieces of 1).
     // A job that fits the slots in ONE round (nothing left to pull: every strong-scaling share of a frame, every small frame) has no
@@ -341,8 +362,8 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     // the streams that happen to share a wavefront with them wait for the same passes.  Such a job is dealt stream by stream (pieces of 1:
     // slot q of wavefront w renders stream q * waves + w), which gives every wavefront a sample of the whole job: the 1/8 share of the
     // benchmark frame 273 -> 221 ms at 256 spp, the 1/4 share 317 -> 259 (profiles/r03_share_rehearsal.txt).
-    const bool single_round = static_cast<uint64_t>(waves) * slots_per_wave >= n && slots_per_wave <= 128U; // (a full grid of 4 rows balances well in pieces of 8: 423 against 409 Msamples/s)
-    uint32_t first_lanes = static_cast<uint32_t>(env_int("PT_FIRST_LANES", single_round ? 1 : 8)); // full frame: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440, 4 -> 431 Msamples/s
+    const bool single_round = plan != nullptr || (static_cast<uint64_t>(waves) * slots_per_wave >= n && slots_per_wave <= 128U); // (a full grid of 4 rows balances well in pieces of 8: 423 against 409 Msamples/s)
+    uint32_t first_lanes = plan != nullptr ? 1U : static_cast<uint32_t>(env_int("PT_FIRST_LANES", single_round ? 1 : 8)); // full frame: 64 -> 402, 32 -> 403, 16 -> 434, 8 -> 440, 4 -> 431 Msamples/s
     if(first_lanes == 0 || first_lanes > 64 || (first_lanes & (first_lanes - 1U)) != 0) {
         first_lanes = single_round ? 1 : 8;
     }
@@ -386,6 +407,7 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg) {
     PT_HIP(s->sl_path_length.ensure(total));
     PT_HIP(s->sl_nee.ensure(static_cast<size_t>(total) * std::max<uint32_t>(rays_per_slot - 1U, 1U)));
     PT_HIP(s->sl_nee_mask.ensure(total));
+    PT_HIP(s->sl_cost.ensure(total));
     PT_HIP(s->sl_est.ensure(total));
     PT_HIP(s->sl_cand.ensure(static_cast<size_t>(total) * PT_MAX_CANDIDATES));
     PT_HIP(s->lq_ray_o.ensure(static_cast<size_t>(waves) * cap));
@@ -427,13 +449,33 @@ int finish_path(pt_scene *s) {
 
 // Render the streams described by T (device pointers) with one launch on the scene's stream.  With a progress function the host polls
 // the count of finished tiles (pinned memory, written by the kernel) while the launch runs and reports every step from the calling thread.
-int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStreams T, float4 *d_image, pt_stats *stats, pt_progress_fn progress, void *progress_user) {
+int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStreams T, float4 *d_image, pt_stats *stats, pt_progress_fn progress, void *progress_user,
+             const PathPlan *plan = nullptr, bool want_costs = false) {
     PtPathConfig cfg;
-    int rc = ensure_path_workspace(s, T.n, &cfg);
+    hipStream_t st = s->stream;
+    PathPlan debug_plan;
+    if(plan == nullptr && !s->debug_place.empty()) {
+        // pt_debug_set_place: this launch only
+        PT_HIP(s->place.ensure(s->debug_place.size()));
+        PT_HIP(hipMemcpyAsync(s->place.ptr, s->debug_place.data(), s->debug_place.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        PT_HIP(hipStreamSynchronize(st));
+        debug_plan.waves = s->debug_place_waves;
+        debug_plan.slots_per_wave = s->debug_place_slots;
+        debug_plan.d_place = s->place.ptr;
+        s->debug_place.clear();
+        plan = &debug_plan;
+    }
+    int rc = ensure_path_workspace(s, T.n, &cfg, plan);
     if(rc != PT_OK) {
         return rc;
     }
-    hipStream_t st = s->stream;
+    want_costs = want_costs || s->debug_collect_costs;
+    T.place = plan != nullptr ? plan->d_place : nullptr;
+    T.cost = nullptr;
+    if(want_costs) {
+        PT_HIP(s->stream_cost.ensure(std::max<uint32_t>(T.n, 1U)));
+        T.cost = s->stream_cost.ptr;
+    }
     PtSlots S{};
     S.total = s->path_slots;
     S.stream = s->sl_stream.ptr;
@@ -449,6 +491,7 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     S.path_length = s->sl_path_length.ptr;
     S.nee = reinterpret_cast<float4 *>(s->sl_nee.ptr);
     S.nee_mask = s->sl_nee_mask.ptr;
+    S.cost = s->sl_cost.ptr;
     S.est = s->sl_est.ptr;
     S.cand = s->sl_cand.ptr;
     PtLocalQueue Q{};
@@ -456,7 +499,7 @@ int run_path(pt_scene *s, const PtDevCamera &cam, const PtDevOptions &opt, PtStr
     Q.ray_d = reinterpret_cast<float4 *>(s->lq_ray_d.ptr);
     Q.cap = s->path_cap;
     T.next = s->pull_counter.ptr;
-    T.first_total = s->path_waves * static_cast<uint32_t>(cfg.slots_per_wave);
+    T.first_total = plan != nullptr ? T.n : s->path_waves * static_cast<uint32_t>(cfg.slots_per_wave); // (a placement names every stream: nothing is left to pull)
     T.n_waves = s->path_waves;
     // The first round (pt_path.hip, stream hand-out): piece q of wavefront w -- `first_lanes` neighbouring slots -- starts on the chunk
     // q * waves + w of as many streams, moved q steps sideways in a regular tile grid.
@@ -1212,6 +1255,36 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
 // Diagnostic, not part of include/pt_hip.h: walks n rays, `lanes_per_wave` of them per wavefront, with every traversal step stamped.
 // out[4 * i ..] = steps, cycles spent waiting for records (flags bit 1: stamped run), cycles of the whole walk, -; flags bit 0: prefetch;
 // behind the n results, 8 segment totals of 8 bytes per ray from a -DPT_STEP_STAMPS build (zeros otherwise): out holds 20 * n words (tools/step_timing.py).
+// Diagnostics of the cost-aware placement (tools/place_probe.py): record what every stream of the following launches costs / read the
+// last launch's costs / give the NEXT launch its first round as a table (waves x slots_per_wave entries, 0xffffffff = empty slot).
+extern "C" int pt_debug_collect_costs(pt_scene *s, int on) {
+    if(s == nullptr) {
+        return fail(PT_ERR_INVALID, "null scene");
+    }
+    s->debug_collect_costs = on != 0;
+    return PT_OK;
+}
+
+extern "C" int pt_debug_stream_costs(pt_scene *s, uint32_t *out, size_t n) {
+    if(s == nullptr || out == nullptr || n > s->stream_cost.count) {
+        return fail(PT_ERR_INVALID, "no costs of that many streams");
+    }
+    PT_HIP(hipSetDevice(s->device));
+    PT_HIP(hipStreamSynchronize(s->stream));
+    PT_HIP(hipMemcpy(out, s->stream_cost.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+extern "C" int pt_debug_set_place(pt_scene *s, uint32_t waves, uint32_t slots_per_wave, const uint32_t *table) {
+    if(s == nullptr || table == nullptr || waves == 0 || waves % 4U != 0 || slots_per_wave == 0) {
+        return fail(PT_ERR_INVALID, "placement table");
+    }
+    s->debug_place.assign(table, table + static_cast<size_t>(waves) * slots_per_wave);
+    s->debug_place_waves = waves;
+    s->debug_place_slots = slots_per_wave;
+    return PT_OK;
+}
+
 extern "C" int pt_debug_step_timing(pt_scene *s, const float *rays, size_t n, int lanes_per_wave, int flags, uint32_t *out) {
     if(s == nullptr || rays == nullptr || out == nullptr || n == 0 || n > 0x3fffffULL || lanes_per_wave < 1 || lanes_per_wave > 64) {
         return fail(PT_ERR_INVALID, "bad argument");

@@ -49,6 +49,7 @@ struct PtSlots {
     int32_t *path_length;  // worker.cpp:43
     float4 *nee;           // [light samples per vertex][total] weighed_spectrum of the pending shadow rays (worker.cpp:97)
     uint32_t *nee_mask;    // which of them wait for their shadow ray (or needed none): bit per light sample
+    uint32_t *cost;        // wave steps the stream's rays spent in traversal so far (only when PtStreams::cost is wanted)
     PtEstimator *est;      // per-pixel estimator (worker.cpp:172-192)
     PtCandidate *cand;     // [total][PT_MAX_CANDIDATES]
 };
@@ -72,6 +73,8 @@ struct PtStreams {
     uint32_t *next;              // global pull counter (alone in its cache line)
     uint32_t *tile_left;         // [n_tiles] pixels of the tile not yet finished, or null: no progress reporting
     uint32_t *tiles_done;        // HOST-visible count of finished tiles (pinned memory), or null
+    uint32_t *cost;              // [n] out, or null: traversal steps of the wavefront that passed while a ray of the stream was walking (summed over its rays)
+    const uint32_t *place;       // [n_waves * slots per wave] or null: the stream that starts in every slot (0xffffffff: none) instead of the arithmetic first round
 };
 
 // Ray queues, one private ring per wavefront: entries [wave * cap, (wave + 1) * cap)

@@ -532,7 +532,12 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
                 ctx.first_rows &= ~(1u << row);
                 base = ctx.first_base + row * 64u;
                 mine = base + lane;
-                if(T.first_spread) {
+                if(T.place != nullptr) {
+                    // an explicit first round (cost-aware placement, pt_api.cpp): the table names the stream of every slot, or none
+                    base = 0;
+                    mine = T.place[ctx.first_base + ls];
+                }
+                else if(T.first_spread) {
                     // piece q of the wavefront (a row, or a part of one) starts on chunk q * waves + w of `first_lanes` streams
                     const uint32_t g = T.first_lanes, q = row * (64u / g) + lane / g;
                     uint32_t chunk = q * T.n_waves + ctx.wave;
@@ -575,6 +580,9 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
                 S.rect[p] = rc;
                 S.rng[p] = r;
                 S.cursor[p] = 0;
+                if(T.cost != nullptr) {
+                    __hip_atomic_store(&S.cost[p], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 flags = PT_F_STREAM;
             }
             else if(want) {
@@ -770,6 +778,9 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
                 const uint32_t si = S.stream[p];
                 if(T.rng != nullptr) {
                     T.rng[si] = rng;
+                }
+                if(T.cost != nullptr) {
+                    T.cost[si] = __hip_atomic_load(&S.cost[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (written by atomics of this wavefront's lanes: read it where they landed)
                 }
                 if(T.tile_left != nullptr) {
                     // progress: the last pixel of a tile reports the tile to the host (processJob's callback, worker.cpp:354-360)
@@ -996,7 +1007,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     }
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // LDS of the workgroup: traversal stacks [STACK_LDS][256] | hit records [4 waves][rows * 64] | slot words [4 waves][rows * 64] |
-    // emitter and material tables (PT_LDS_TABLE_BYTES) | (small scenes) the whole tree and all triangle records
+    // emitter and material tables (PT_LDS_TABLE_BYTES) | start step of every lane's walk | (small scenes) the whole tree and all triangle records
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
     const uint32_t wave_in_block = (uint32_t)tid >> 6;
@@ -1017,7 +1028,11 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     at += (size_t)PT_LDS_TABLE_MAX * 6 * sizeof(float4);
     float4 *materials_l = reinterpret_cast<float4 *>(at);
     at += (size_t)PT_LDS_TABLE_MAX * 4 * sizeof(float4);
+    uint32_t __attribute__((address_space(3))) *born_l = (uint32_t __attribute__((address_space(3))) *)reinterpret_cast<uint32_t *>(at) + tid; // wave step at which the lane's walk began
+    at += (size_t)256 * sizeof(uint32_t);
     float4 *lds_recs = reinterpret_cast<float4 *>(at); // (small scenes) every record, in the order of `recs`
+    const bool cost_on = A->T.cost != nullptr;
+    uint32_t *const slot_cost = A->S.cost;
 
     ShadeTables tb;
     tb.emis.cdf_l = (const float __attribute__((address_space(3))) *)cdf_l;
@@ -1212,6 +1227,11 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                     hit_l[ls] = h;
                     __hip_atomic_fetch_add(&word_l[ls], (typename SW::T)0 - SW::one_ray(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                if(cost_on) {
+                    // what the stream cost: the steps this wavefront made while the ray was walking (a stream's rays follow one another,
+                    // so their sum is the length of its chain in steps)
+                    __hip_atomic_fetch_add(&slot_cost[slot_base + ls], w_steps - *born_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 active = false;
             }
 
@@ -1247,6 +1267,9 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                     const float4 rd = make_float4(__shfl(win_d.x, src), __shfl(win_d.y, src), __shfl(win_d.z, src), __shfl(win_d.w, src));
                     if(!active && rank < take && __float_as_uint(rd.w) != PT_DEST_NULL) {
                         tr.start(w, rec, root, ro, rd);
+                        if(cost_on) {
+                            *born_l = w_steps;
+                        }
                         active = true;
                         n_rays++;
                         n_shadow += (w.dest & PT_DEST_SHADOW) ? 1u : 0u;
@@ -1655,7 +1678,7 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
 
 size_t pt_path_lds_bytes(int wide, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
     const size_t scene = ((size_t)n_lds_pairs + n_lds_leaf_records) * 64;
-    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t))) + PT_LDS_TABLE_BYTES + scene;
+    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t))) + PT_LDS_TABLE_BYTES + 256 * sizeof(uint32_t) + scene;
 }
 
 int pt_path_blocks_per_cu(int wide, int in_lds, size_t lds_bytes) {

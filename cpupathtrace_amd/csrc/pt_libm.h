@@ -7,6 +7,13 @@
 //   sinf/cosf  sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h, s_sincosf_data.c   (double polynomial, |x| < 120 paths)
 //   powf       sysdeps/ieee754/flt-32/e_powf.c, e_powf_log2_data.c, e_exp2f_data.c          (x >= 0 finite, no overflow paths)
 //   acosf      sysdeps/ieee754/flt-32/e_acosf.c                                             (fdlibm, pure fp32)
+// Provenance and licence.  The algorithms and the numerical tables below (polynomial coefficients, the 2^(i/32) and log2 tables,
+// the 4/pi bits of the range reduction) are those of the files named above, written out again for this header: no glibc source
+// text is included, but the constants are necessarily the same numbers.  glibc is distributed under the GNU Lesser General Public
+// License, version 2.1 or later (Copyright (C) Free Software Foundation, Inc.; s_sinf.c / s_cosf.c / s_sincosf*.c / e_powf*.c /
+// e_exp2f_data.c were contributed by Arm Ltd.); e_acosf.c derives from fdlibm ("Copyright (C) 1993 by Sun Microsystems, Inc.
+// ... Permission to use, copy, modify, and distribute this software is freely granted, provided that this notice is preserved.").
+// Anyone redistributing this header in a product should treat it as a derived numerical restatement of LGPL-2.1+ / fdlibm code.
 // They use only IEEE +,-,*,/,sqrt in fp32/fp64 and integer operations, which gfx950 executes bit-identically to x86-64
 // as long as the compiler does not contract a*b+c into an fma (-ffp-contract=off; glibc's non-FMA build is the model).
 // tests/test_libm_restated.py compiles this header for the host and compares it with the running glibc over the whole

@@ -309,7 +309,6 @@ int setup_path(pt_scene *s) {
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 12), 1), 64);
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
     cfg.ready_shift = std::min(std::max(env_int("PT_READY_SHIFT", 1), 0), 31);
-    cfg.prefetch = env_int("PT_PREFETCH", 0) != 0 ? 1 : 0;
     // (burst_steps and leaf_min depend on the job's size as well: ensure_path_workspace sets them per job and keeps the last job's here)
     cfg.burst_steps = 24;
     cfg.leaf_min = 8;
@@ -1253,7 +1252,7 @@ int pt_intersect_batch(pt_scene *s, const float *rays, size_t n, float *out_t, i
 }
 
 // Diagnostic, not part of include/pt_hip.h: walks n rays, `lanes_per_wave` of them per wavefront, with every traversal step stamped.
-// out[4 * i ..] = steps, cycles spent waiting for records (flags bit 1: stamped run), cycles of the whole walk, -; flags bit 0: prefetch;
+// out[4 * i ..] = steps, cycles spent waiting for records (flags bit 1: stamped run), cycles of the whole walk, -; flags bit 0: unused;
 // behind the n results, 8 segment totals of 8 bytes per ray from a -DPT_STEP_STAMPS build (zeros otherwise): out holds 20 * n words (tools/step_timing.py).
 // Diagnostics of the cost-aware placement (tools/place_probe.py): record what every stream of the following launches costs / read the
 // last launch's costs / give the NEXT launch its first round as a table (waves x slots_per_wave entries, 0xffffffff = empty slot).

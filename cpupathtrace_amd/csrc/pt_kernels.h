@@ -100,7 +100,6 @@ struct PtPathConfig {
     int ready_shift;      // ... or (slots that still hold or may get a stream) >> ready_shift, if that is less: a wavefront whose last streams are running shades them as they come
     int burst_steps;      // traversal steps between two looks at the queue
     int first_lanes;      // slots per piece of the first round of streams (slots_per_wave is a multiple of it)
-    int prefetch;         // a walk requests the line of a node's inner children as soon as it stands on the node (pt_path.hip, Tracer::step)
     int leaf_min;         // lanes that must stand on a leaf before the leaf code runs (while other lanes still have nodes to visit)
     unsigned long long *wave_counters; // [grid * 4 waves][8] node visits, leaf tests, rays, shadow rays, wave steps, shading passes, samples, vertices
 };
@@ -115,7 +114,7 @@ struct PtPathArgs {
     PtSlots S;
     PtStreams T;
     PtLocalQueue Q;
-    int rows, slots_per_wave, refill_idle, min_ready, burst_steps, leaf_min, ready_shift, prefetch;
+    int rows, slots_per_wave, refill_idle, min_ready, burst_steps, leaf_min, ready_shift;
     uint2 *spill;
     uint32_t spill_depth;
     uint32_t save_stride;
@@ -136,7 +135,7 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
                      uint2 *spill, unsigned long long *out);
 void pt_launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg);
 // diagnostic (tools/step_timing.py): stamped walks, `lanes_per_wave` rays per wavefront; out[ray] = (steps, cycles waiting for records, cycles in all, price of a stamp pair)
-void pt_launch_steptime(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint32_t lanes_per_wave, uint4 *out, uint2 *spill, uint32_t spill_depth, int prefetch);
+void pt_launch_steptime(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint32_t lanes_per_wave, uint4 *out, uint2 *spill, uint32_t spill_depth, int flags);
 
 
 #endif

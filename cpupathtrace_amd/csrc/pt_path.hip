@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
 // Scene::getIntersection for a batch of rays: one walk per lane, the same traversal machinery
 template<int STACK_LDS, bool IN_LDS>
 __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const float *__restrict__ rays6, uint32_t n, uint2 *__restrict__ out, uint2 *__restrict__ spill,
-                                                         uint32_t spill_depth, int prefetch) {
+                                                         uint32_t spill_depth) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     lds_u2_ptr stack_l = (lds_u2_ptr)reinterpret_cast<uint2 *>(lds_raw) + tid;
@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(256) void pt_closest_kernel(PtDevScene sc, const fl
 // out[ray] = (steps, cycles waiting for records, cycles of the whole walk, cycles of two back-to-back stamps = the stamps' own price).
 template<int STACK_LDS, bool STAMP>
 __global__ __launch_bounds__(256) void pt_steptime_kernel(PtDevScene sc, const float *__restrict__ rays6, uint32_t n, uint32_t lanes_per_wave, uint4 *__restrict__ out,
-                                                          uint2 *__restrict__ spill, uint32_t spill_depth, int prefetch) {
+                                                          uint2 *__restrict__ spill, uint32_t spill_depth) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(256) void pt_steptime_kernel(PtDevScene sc, const f
 template<int STACK_LDS, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void pt_replay_kernel(PtDevScene sc, PtLocalQueue Q, uint32_t n_logs, uint32_t parts, int refill_idle, int burst_steps,
                                                                 int leaf_min, uint2 *__restrict__ spill, uint32_t spill_depth,
-                                                                unsigned long long *__restrict__ out, int prefetch) {
+                                                                unsigned long long *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
@@ -1571,7 +1571,7 @@ int launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueu
     }
     const uint32_t waves = n_logs * parts;
     hipLaunchKernelGGL((pt_replay_kernel<STACK_LDS, WAVES>), dim3((waves + 3) / 4), dim3(256), lds, stream, scene, Q, n_logs, parts, cfg.refill_idle,
-                       cfg.burst_steps, cfg.leaf_min, spill, cfg.spill_depth, out, cfg.prefetch);
+                       cfg.burst_steps, cfg.leaf_min, spill, cfg.spill_depth, out);
     return blocks;
 }
 
@@ -1590,7 +1590,7 @@ int occupancy(size_t lds_bytes) {
 template<int STACK_LDS, bool IN_LDS>
 void launch_closest(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint2 *out, const PtPathConfig &cfg) {
     const size_t lds = (size_t)STACK_LDS * 256 * sizeof(uint2) + (IN_LDS ? ((size_t)scene.n_lds_pairs + scene.pair_base) * 64 : 0);
-    hipLaunchKernelGGL((pt_closest_kernel<STACK_LDS, IN_LDS>), dim3((n + 255) / 256), dim3(256), lds, stream, scene, rays6, n, out, cfg.spill, cfg.spill_depth, cfg.prefetch);
+    hipLaunchKernelGGL((pt_closest_kernel<STACK_LDS, IN_LDS>), dim3((n + 255) / 256), dim3(256), lds, stream, scene, rays6, n, out, cfg.spill, cfg.spill_depth);
 }
 
 } // namespace
@@ -1631,7 +1631,6 @@ void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCame
     a.burst_steps = cfg.burst_steps;
     a.leaf_min = cfg.leaf_min;
     a.ready_shift = cfg.ready_shift;
-    a.prefetch = cfg.prefetch;
     a.spill = cfg.spill;
     a.spill_depth = cfg.spill_depth;
     a.save_stride = (uint32_t)cfg.grid * 256u;
@@ -1643,13 +1642,13 @@ void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCame
     PT_DISPATCH_PATH(launch_path, cfg, stream, cfg, d_args);
 }
 
-void pt_launch_steptime(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint32_t lanes_per_wave, uint4 *out, uint2 *spill, uint32_t spill_depth, int prefetch) {
+void pt_launch_steptime(hipStream_t stream, const PtDevScene &scene, const float *rays6, uint32_t n, uint32_t lanes_per_wave, uint4 *out, uint2 *spill, uint32_t spill_depth, int flags) {
     const uint32_t waves = (n + lanes_per_wave - 1) / lanes_per_wave;
-    if(prefetch & 2) { // bit 1: stamp the waits (each stamp is a scalar memory round trip of its own: the totals of such a run are inflated)
-        hipLaunchKernelGGL((pt_steptime_kernel<8, true>), dim3((waves + 3) / 4), dim3(256), (size_t)8 * 256 * sizeof(uint2), stream, scene, rays6, n, lanes_per_wave, out, spill, spill_depth, prefetch & 1);
+    if(flags & 2) { // bit 1: stamp the waits (each stamp is a scalar memory round trip of its own: the totals of such a run are inflated)
+        hipLaunchKernelGGL((pt_steptime_kernel<8, true>), dim3((waves + 3) / 4), dim3(256), (size_t)8 * 256 * sizeof(uint2), stream, scene, rays6, n, lanes_per_wave, out, spill, spill_depth);
     }
     else {
-        hipLaunchKernelGGL((pt_steptime_kernel<8, false>), dim3((waves + 3) / 4), dim3(256), (size_t)8 * 256 * sizeof(uint2), stream, scene, rays6, n, lanes_per_wave, out, spill, spill_depth, prefetch & 1);
+        hipLaunchKernelGGL((pt_steptime_kernel<8, false>), dim3((waves + 3) / 4), dim3(256), (size_t)8 * 256 * sizeof(uint2), stream, scene, rays6, n, lanes_per_wave, out, spill, spill_depth);
     }
 }
 

@@ -1,8 +1,9 @@
 """What the traversal alone delivers on the rays of a real frame, at 4..8 wavefronts per SIMD (the path kernel is held at 4 by the
 shading code's registers).  Renders the benchmark scene with rings that never wrap (PT_RING_LOG_RAYS), then replays the logged rays
 with pt_debug_replay_rays (same hand-out / burst / leaf-batching loop, no shading).
-    python tools/replay_probe.py [mesh_n] [spp]        PT_PROBE_LAYOUT=k: first rewrite the pair records in treelets of k levels
-(pt_debug_relayout_pairs; k = 1 is a depth-first pre-order; the frame must not change -- its hash is printed)"""
+    python tools/replay_probe.py [mesh_n] [spp]
+(Round 2 could first rewrite the pair records in treelets of k levels -- every layout within 1 % of breadth-first,
+profiles/r02_layout_probe.txt; the records are one linked array since round 3 and that diagnostic is gone.)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PT_RING_LOG_RAYS"] = os.environ.get("PT_RING_LOG_RAYS", "65536")
@@ -12,13 +13,6 @@ mesh_n = int(sys.argv[1]) if len(sys.argv) > 1 else 1900
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 sc, cam = scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(mesh_n, mesh_n, scenes.DRAGON_BOX_TRANSFORM))
 s = binding.Scene(sc)
-layout = int(os.environ.get("PT_PROBE_LAYOUT", "0"))
-if layout > 0:
-    rl = binding.load().pt_debug_relayout_pairs
-    rl.restype = ctypes.c_int
-    rl.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    assert rl(s._h, layout) == 0, binding.load().pt_last_error()
-    print("pair records laid out in treelets of %d levels" % layout, flush=True)
 img, st = s.process_job(cam, scenes.options(1024, 1024, spp, spp), want_stats=True)
 import hashlib
 print("frame sha1", hashlib.sha1(img.tobytes()).hexdigest()[:16], flush=True)

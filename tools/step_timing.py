@@ -40,7 +40,7 @@ def run(rays, lanes, flags, segments=False):
 for label, win in (("window on the mesh", (-0.05, 0.05, -0.21, -0.11)), ("whole frame", (-0.33, 0.33, -0.33, 0.33))):
     for n, lanes in ((256, 1), (4096, 1), (4096, 64), (262144, 64)):
         rays = rays_through(*win, n)
-        for pf in (0, 1):
+        for pf in (0,):  # (bit 0 of the flags was the children-line prefetch of an experiment: gone)
             run(rays, lanes, pf)
             clean = run(rays, lanes, pf)
             stamped = run(rays, lanes, pf | 2)
@@ -55,6 +55,6 @@ for label, win in (("window on the mesh", (-0.05, 0.05, -0.21, -0.11)), ("whole 
                 price = seg[:, 7].sum() / st
                 print("    stamped build, cycles per step (a stamp's own round trip, %.0f, taken off each): " % price +
                       "; ".join("%s %.0f" % (SEGMENTS[k], seg[:, k].sum() / st - price) for k in range(7)), flush=True)
-            print("%-18s %6d rays, %2d per wavefront, %5d wavefronts (%4.1f per SIMD), prefetch %d: %5.1f steps per walk, %6.0f cycles per step; stamped run: %5.0f of them waiting for the record" % (
-                label, n, lanes, waves, min(waves / 1024.0, 8.0), pf, steps / waves, total / steps, wait / steps), flush=True)
+            print("%-18s %6d rays, %2d per wavefront, %5d wavefronts (%4.1f per SIMD): %5.1f steps per walk, %6.0f cycles per step; stamped run: %5.0f of them waiting for the record" % (
+                label, n, lanes, waves, min(waves / 1024.0, 8.0), steps / waves, total / steps, wait / steps), flush=True)
 s.close()

@@ -679,3 +679,37 @@ def test_more_than_32_light_samples_are_refused():
     with pytest.raises(binding.PtError) as e:
         binding.Scene(desc)
     assert e.value.code == 4 and "more than 32 light samples" in str(e.value) and "31 point lights + 2 emitter samples" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_frame_independent_of_first_round_placement(gpu_scenes, sset):
+    """The diagnostics behind DESIGN.md 5.1's placement experiments: a first round of streams made by the caller (pt_debug_set_place: which
+    stream starts in which slot of which wavefront, with empty slots) must render the same frame bit for bit as the library's own, and the
+    cost counters (pt_debug_collect_costs: wave steps while a ray of the stream walks) must cover every stream."""
+    import ctypes as C
+    lib = binding.load()
+    desc, cam = sset["meshbox"]
+    gpu = gpu_scenes("meshbox")
+    w = h = 96
+    opt = scenes.options(w, h, 6, 6)
+    want, _ = gpu.process_job(cam, opt, base_seed=77, want_stats=True)
+    want = want.copy()
+    n = w * h
+    rng = np.random.default_rng(5)
+    waves, slots = 512, 40
+    table = np.full(waves * slots, 0xFFFFFFFF, np.uint32)
+    table[rng.permutation(waves * slots)[:n]] = rng.permutation(n).astype(np.uint32)  # any stream anywhere, more than half of the slots empty
+    binding._check(lib.pt_debug_collect_costs(gpu._h, 1))
+    try:
+        binding._check(lib.pt_debug_set_place(gpu._h, C.c_uint32(waves), C.c_uint32(slots), table.ctypes.data_as(C.c_void_p)))
+        got, st = gpu.process_job(cam, opt, base_seed=77, want_stats=True)
+        assert_bits_equal(got, want, "frame under a caller-made first round")
+        assert st["wavefronts"] == waves and st["samples"] == 6 * n
+        costs = np.zeros(n, np.uint32)
+        binding._check(lib.pt_debug_stream_costs(gpu._h, costs.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+        assert (costs > 0).mean() > 0.99, "(nearly) every stream walked a ray for at least one step"
+        # (the table is used once: the next call is the library's own first round again)
+        again, st2 = gpu.process_job(cam, opt, base_seed=77, want_stats=True)
+        assert_bits_equal(again, want, "frame after the table was used")
+    finally:
+        binding._check(lib.pt_debug_collect_costs(gpu._h, 0))

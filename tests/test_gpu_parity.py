@@ -713,3 +713,24 @@ def test_frame_independent_of_first_round_placement(gpu_scenes, sset):
         assert_bits_equal(again, want, "frame after the table was used")
     finally:
         binding._check(lib.pt_debug_collect_costs(gpu._h, 0))
+
+
+@pytest.mark.gpu
+def test_every_device_of_the_host_renders_its_tiles(sset):
+    """pt_render_tiles_multi with one scene PER DEVICE (what $PATHTRACE_DEVICES / doWorkParallel over GPUs does, src/host/scene.cpp): the
+    frame equals the single-device frame and every device renders samples.  Needs two GPUs in one process: skipped on a one-GPU box
+    (there the same code path runs with two replicas on device 0, test_progress_and_replicas); multi-GPU hardware runs are the driver's."""
+    n_dev = binding.device_count()
+    if n_dev < 2:
+        pytest.skip("one HIP device on this host")
+    desc, cam = sset["meshbox"]
+    opt = scenes.options(256, 192, 8, 8)
+    replicas = [binding.Scene(desc, device=d) for d in range(min(n_dev, 8))]
+    try:
+        want = replicas[0].process_job(cam, opt, base_seed=31)
+        img, stats = binding.process_job_multi(replicas, cam, opt, base_seed=31, want_stats=True)
+        assert_bits_equal(img, want, "frame rendered by %d devices" % len(replicas))
+        assert sum(s["samples"] for s in stats) == 256 * 192 * 8 and all(s["samples"] > 0 for s in stats)
+    finally:
+        for r in replicas:
+            r.close()

@@ -983,6 +983,9 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
 // ---- the kernel -------------------------------------------------------------------------------------------------------------------------
 
 #define PT_PATH_STACK_LDS 8 /* entries of a lane's traversal stack kept in LDS (16 KB per workgroup: four workgroups share a CU); deeper ones spill to HBM */
+#ifndef PT_COST_LDS_BYTES
+#define PT_COST_LDS_BYTES 1024 /* one word per lane: the wave step at which its walk began (stream cost diagnostics); 0 in builds that need the LDS */
+#endif
 #ifndef PT_PATH_WAVES
 #define PT_PATH_WAVES 4 /* 128 VGPRs: the traversal loop has no spills there; three waves per SIMD hide less of the node-fetch latency (profiles/) */
 #endif
@@ -1029,9 +1032,9 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     float4 *materials_l = reinterpret_cast<float4 *>(at);
     at += (size_t)PT_LDS_TABLE_MAX * 4 * sizeof(float4);
     uint32_t __attribute__((address_space(3))) *born_l = (uint32_t __attribute__((address_space(3))) *)reinterpret_cast<uint32_t *>(at) + tid; // wave step at which the lane's walk began
-    at += (size_t)256 * sizeof(uint32_t);
+    at += (size_t)PT_COST_LDS_BYTES;
     float4 *lds_recs = reinterpret_cast<float4 *>(at); // (small scenes) every record, in the order of `recs`
-    const bool cost_on = A->T.cost != nullptr;
+    const bool cost_on = PT_COST_LDS_BYTES != 0 && A->T.cost != nullptr;
     uint32_t *const slot_cost = A->S.cost;
 
     ShadeTables tb;
@@ -1677,7 +1680,7 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
 
 size_t pt_path_lds_bytes(int wide, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
     const size_t scene = ((size_t)n_lds_pairs + n_lds_leaf_records) * 64;
-    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t))) + PT_LDS_TABLE_BYTES + 256 * sizeof(uint32_t) + scene;
+    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t))) + PT_LDS_TABLE_BYTES + PT_COST_LDS_BYTES + scene;
 }
 
 int pt_path_blocks_per_cu(int wide, int in_lds, size_t lds_bytes) {

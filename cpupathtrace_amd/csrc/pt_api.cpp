@@ -309,6 +309,9 @@ int setup_path(pt_scene *s) {
     cfg.refill_idle = std::min(std::max(env_int("PT_REFILL_IDLE", 12), 1), 64);
     cfg.min_ready = std::min(std::max(env_int("PT_MIN_READY", 32), 1), 64 * PT_MAX_ROWS);
     cfg.ready_shift = std::min(std::max(env_int("PT_READY_SHIFT", 1), 0), 31);
+    cfg.pass_q_low = std::max(env_int("PT_PASS_Q_LOW", 0), 0);
+    cfg.early_ready = std::min(std::max(env_int("PT_EARLY_READY", 0), 0), 64 * PT_MAX_ROWS);
+    cfg.compact_passes = env_int("PT_COMPACT", 1) != 0 ? 1 : 0;
     // (burst_steps and leaf_min depend on the job's size as well: ensure_path_workspace sets them per job and keeps the last job's here)
     cfg.burst_steps = 24;
     cfg.leaf_min = 8;

@@ -98,6 +98,9 @@ struct PtPathConfig {
     int refill_idle;      // idle lanes that make a wavefront refill from its queue (or shade when the queue is empty)
     int min_ready;        // slots that must be ready before a wavefront with walks in progress stops tracing to shade ...
     int ready_shift;      // ... or (slots that still hold or may get a stream) >> ready_shift, if that is less: a wavefront whose last streams are running shades them as they come
+    int pass_q_low;       // a pass may also start while the ring still holds rays, if it holds at most this many ...
+    int early_ready;      // ... and this many slots are ready (0 = never: a pass waits for the ring to run empty)
+    int compact_passes;   // a pass whose ready slots fit fewer chunks of 64 than they occupy rows runs over a list of them (pt_path.hip)
     int burst_steps;      // traversal steps between two looks at the queue
     int first_lanes;      // slots per piece of the first round of streams (slots_per_wave is a multiple of it)
     int leaf_min;         // lanes that must stand on a leaf before the leaf code runs (while other lanes still have nodes to visit)
@@ -114,7 +117,7 @@ struct PtPathArgs {
     PtSlots S;
     PtStreams T;
     PtLocalQueue Q;
-    int rows, slots_per_wave, refill_idle, min_ready, burst_steps, leaf_min, ready_shift;
+    int rows, slots_per_wave, refill_idle, min_ready, burst_steps, leaf_min, ready_shift, pass_q_low, early_ready, compact_passes;
     uint2 *spill;
     uint32_t spill_depth;
     uint32_t save_stride;

@@ -432,6 +432,7 @@ struct SlotWord<true> {
 };
 
 #define PT_DEST_SLOT_MASK 0xffffu
+#define PT_NO_SLOT 0xffffffffu
 #define PT_DEST_J_SHIFT 16
 
 // What a wavefront keeps about itself (everything wave-uniform).
@@ -498,9 +499,11 @@ struct ShadeTables {
 // give every lane its position; rays of one kind from neighbouring pixels end up in neighbouring lanes of the traversal).
 template<bool WIDE>
 PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOptions &opt, const PtSlots &S, const PtStreams &T, const PtLocalQueue &Q,
-                    WaveCtx &ctx, uint32_t row, uint32_t lane, size_t slot_base, size_t queue_base, typename SlotWord<WIDE>::lds_ptr word_l, lds_u2_ptr hit_l,
+                    WaveCtx &ctx, uint32_t row, uint32_t ls_in, uint32_t lane, size_t slot_base, size_t queue_base, typename SlotWord<WIDE>::lds_ptr word_l, lds_u2_ptr hit_l,
                     float4 *__restrict__ image, PtDevCounters *counters, const ShadeTables &tb, uint32_t &n_samples, uint32_t &n_vertices) {
-    const uint32_t ls = row * 64 + lane; // slot of the wave
+    // the lane's slot of the wave: lane `lane` of row `row`, or -- in a compacted pass (see the kernel) -- the slot the list names; PT_NO_SLOT = none
+    const bool have_slot = ls_in != PT_NO_SLOT;
+    const uint32_t ls = have_slot ? ls_in : 0u;
     const size_t p = slot_base + ls;     // slot of the grid
     const unsigned long long lt = (1ULL << lane) - 1ULL;
     const uint32_t n_light_samples = sc.n_lights + sc.n_object_samples;
@@ -508,7 +511,7 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
     const typename SW::T word = word_l[ls];
     uint32_t flags = SW::flags(word);
     const uint32_t vis_bits = SW::vis(word);
-    bool ready = !(flags & PT_F_DONE) && SW::pending(word) == 0;
+    bool ready = have_slot && !(flags & PT_F_DONE) && SW::pending(word) == 0;
     if(__ballot(ready) == 0ULL) {
         return;
     }
@@ -1000,7 +1003,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     const PtPathArgs *A = (const PtPathArgs *)A4;
     // what the traversal loop needs, read once
     const int rows = A->rows, slots_per_wave = A->slots_per_wave, refill_idle = A->refill_idle, min_ready = A->min_ready, burst_steps = A->burst_steps,
-              leaf_min = A->leaf_min, ready_shift = A->ready_shift;
+              leaf_min = A->leaf_min, ready_shift = A->ready_shift, pass_q_low = A->early_ready > 0 ? A->pass_q_low : 0, early_ready = A->early_ready;
     PtLocalQueue Q = A->Q;
     RootBox root;
     root.ref = A->sc.root_ref;
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
         root.hi[k] = A->sc.root_hi[k];
     }
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    // LDS of the workgroup: traversal stacks [STACK_LDS][256] | hit records [4 waves][rows * 64] | slot words [4 waves][rows * 64] |
+    // LDS of the workgroup: traversal stacks [STACK_LDS][256] | hit records [4 waves][rows * 64] | slot words [4 waves][rows * 64] | ready lists [4 waves][rows * 64] |
     // emitter and material tables (PT_LDS_TABLE_BYTES) | start step of every lane's walk | (small scenes) the whole tree and all triangle records
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
@@ -1023,6 +1026,9 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     at += (size_t)4 * n_slots * sizeof(uint2);
     typename SW::lds_ptr word_l = (typename SW::lds_ptr)reinterpret_cast<typename SW::T *>(at) + wave_in_block * n_slots;
     at += (size_t)4 * n_slots * sizeof(typename SW::T);
+    typedef unsigned short __attribute__((address_space(3))) *lds_u16_ptr;
+    lds_u16_ptr list_l = (lds_u16_ptr)reinterpret_cast<unsigned short *>(at) + wave_in_block * n_slots; // the ready slots of a compacted pass
+    at += (size_t)4 * n_slots * sizeof(unsigned short);
     float *cdf_l = reinterpret_cast<float *>(at);
     at += (size_t)PT_LDS_TABLE_MAX * sizeof(float);
     float4 *emis_l = reinterpret_cast<float4 *>(at);
@@ -1168,9 +1174,37 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                 sv[15 * st] = n_rays;
                 sv[16 * st] = n_shadow;
             }
+            // A pass costs a chain of memory round trips per ROW it visits, however few of the row's slots take part.  Once streams end
+            // for good (adaptive sampling stops pixels early; the last streams of any job) the ready slots thin out in every row alike, so
+            // when they fit fewer chunks of 64 than they occupy rows, the pass runs over a LIST of them instead (slot numbers in LDS, in
+            // slot order): lane i of chunk k shades the (64 k + i)-th ready slot.  Its state accesses are gathers then, which is why a
+            // well-filled pass keeps the rows.  (The first round of streams is dealt by row: no list before every row has had its turn.)
+            uint32_t n_listed = 0;
+            bool compact = false;
+            if(P->compact_passes != 0 && rows > 1 && ctx.first_rows == 0u) {
+                uint32_t rows_used = 0;
+                for(uint32_t r = 0; r < (uint32_t)rows; r++) {
+                    const typename SW::T word = word_l[r * 64 + lane];
+                    const bool is_ready = !(SW::flags(word) & PT_F_DONE) && SW::pending(word) == 0;
+                    const unsigned long long m = __ballot(is_ready);
+                    if(is_ready) {
+                        list_l[n_listed + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = (unsigned short)(r * 64 + lane);
+                    }
+                    n_listed += (uint32_t)__popcll(m);
+                    rows_used += m != 0ULL ? 1u : 0u;
+                }
+                compact = (n_listed + 63u) / 64u < rows_used;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // (the list is read by other lanes of this wavefront)
+            }
+            const uint32_t n_chunks = compact ? (n_listed + 63u) / 64u : (uint32_t)rows;
 #pragma unroll 1
-            for(uint32_t r = 0; r < (uint32_t)rows; r++) {
-                shade_row<WIDE>(P->sc, P->cam, P->opt, P->S, P->T, P->Q, ctx, r, lane, slot_base, queue_base, word_l, hit_l, P->image, P->counters, tb, n_samples, n_vertices);
+            for(uint32_t k = 0; k < n_chunks; k++) {
+                // (in a compacted pass `row` is not used: the first round is over)
+                uint32_t ls = k * 64u + lane;
+                if(compact) {
+                    ls = ls < n_listed ? (uint32_t)list_l[ls] : PT_NO_SLOT;
+                }
+                shade_row<WIDE>(P->sc, P->cam, P->opt, P->S, P->T, P->Q, ctx, k, ls, lane, slot_base, queue_base, word_l, hit_l, P->image, P->counters, tb, n_samples, n_vertices);
             }
             // the rays just written are read back by other lanes of this wavefront
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1242,7 +1276,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
             const unsigned long long idle_mask = __ballot(!active);
             const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
             if(n_idle >= (uint32_t)refill_idle) {
-                if(ctx.q_count == 0 && ctx.n_dead < n_slots) {
+                if(ctx.q_count <= (uint32_t)pass_q_low && ctx.n_dead < n_slots) {
                     // slots whose rays have all come back (or that wait for a stream)
                     uint32_t n_ready = 0;
                     for(uint32_t r = 0; r < (uint32_t)rows; r++) {
@@ -1254,7 +1288,9 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                     // long as its slowest stream)
                     const uint32_t live_share = (n_slots - ctx.n_dead) >> ready_shift;
                     const uint32_t need = live_share < (uint32_t)min_ready ? (live_share > 1u ? live_share : 1u) : (uint32_t)min_ready;
-                    if(n_ready >= need || n_idle == 64u) {
+                    // (with rays left in the ring -- pass_q_low > 0 -- the pass is an early one: it tops the ring up before the lanes run dry, and
+                    // is only worth its fixed price when `early_ready` slots take part)
+                    if(ctx.q_count == 0 ? (n_ready >= need || n_idle == 64u) : n_ready >= (uint32_t)early_ready) {
                         want_pass = true;
                         break;
                     }
@@ -1634,6 +1670,9 @@ void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCame
     a.burst_steps = cfg.burst_steps;
     a.leaf_min = cfg.leaf_min;
     a.ready_shift = cfg.ready_shift;
+    a.pass_q_low = cfg.pass_q_low;
+    a.early_ready = cfg.early_ready;
+    a.compact_passes = cfg.compact_passes;
     a.spill = cfg.spill;
     a.spill_depth = cfg.spill_depth;
     a.save_stride = (uint32_t)cfg.grid * 256u;
@@ -1680,7 +1719,7 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
 
 size_t pt_path_lds_bytes(int wide, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
     const size_t scene = ((size_t)n_lds_pairs + n_lds_leaf_records) * 64;
-    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t))) + PT_LDS_TABLE_BYTES + PT_COST_LDS_BYTES + scene;
+    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t)) + sizeof(unsigned short)) + PT_LDS_TABLE_BYTES + PT_COST_LDS_BYTES + scene;
 }
 
 int pt_path_blocks_per_cu(int wide, int in_lds, size_t lds_bytes) {

@@ -734,3 +734,48 @@ def test_every_device_of_the_host_renders_its_tiles(sset):
     finally:
         for r in replicas:
             r.close()
+
+
+def _scene_with_env(desc, **env):
+    """binding.Scene(desc) under the given environment (the library reads its knobs when a scene is created)."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return binding.Scene(desc)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
+def test_compacted_passes_render_the_same_frame(oracle_lib):
+    """Adaptive sampling thins out the slots of every wavefront (pixels stop at different samples and a 1024 x 1024 job has no stream left to
+    take their place); a shading pass then runs over a LIST of the ready slots instead of the rows they sit in (pt_path.hip, the pass loop).
+    Which lane shades which slot must not matter: the frame equals the one rendered row by row (PT_COMPACT=0) bit for bit, both with the
+    tree in HBM and with the scene in LDS, and equals the oracle on sampled pixels."""
+    cases = [("mesh80k", scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(200, 200, scenes.DRAGON_BOX_TRANSFORM)), scenes.options(1024, 1024, 4, 24)),
+             ("box", scenes.box_scene(), scenes.options(1024, 1024, 8, 40))]
+    for name, (desc, cam), opt in cases:
+        by_rows = _scene_with_env(desc, PT_COMPACT=0)
+        by_list = _scene_with_env(desc, PT_COMPACT=1)
+        handle = oracle_lib.scene_create(desc)
+        try:
+            want, st_rows = by_rows.process_job(cam, opt, base_seed=91, want_stats=True)
+            want = want.copy()
+            assert st_rows["samples"] < 1024 * 1024 * opt["max_sample_count"], "%s: no pixel stopped early, the case tests nothing" % name
+            got, st_list = by_list.process_job(cam, opt, base_seed=91, want_stats=True)
+            assert_bits_equal(got, want, "%s: frame of compacted passes against row-by-row passes" % name)
+            assert st_list["samples"] == st_rows["samples"] and st_list["vertices"] == st_rows["vertices"]
+            rng = np.random.default_rng(17)
+            xs, ys = rng.integers(0, 1024, 1000).astype(np.int32), rng.integers(0, 1024, 1000).astype(np.int32)
+            states = np.array([binding.seed_to_state(binding.pixel_seed(91, int(x), int(y))) for x, y in zip(xs, ys)], np.uint64)
+            ref, _ = handle.render_streams(cam, opt, oracle.pixel_streams(xs, ys, states), n_threads=16)
+            assert_bits_equal(got[ys, xs], ref[ys, xs], "%s: sampled pixels against the oracle" % name)
+        finally:
+            by_rows.close()
+            by_list.close()
+            handle.close()

@@ -1,6 +1,9 @@
 """Knob sweep on one scene (the environment is read when a Scene is created).
 
-    python tools/sweep.py <mesh_n | 0 = cornell | -1 = box> <spp> "<list of dicts of env settings, or a dict of lists (grid)>" [size]
+    python tools/sweep.py <mesh_n | 0 = cornell | -1 = box> <spp> "<list of dicts of env settings, or a dict of lists (grid)>" [size] [min_spp]
+
+With min_spp < spp the per-pixel estimator may stop early (adaptive sampling); the rate is then on the max-spp basis and the share of
+the samples really drawn is printed.
 """
 import itertools, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +14,7 @@ mesh_n = int(sys.argv[1]) if len(sys.argv) > 1 else 1900
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 spec = eval(sys.argv[3]) if len(sys.argv) > 3 else [{}]
 size = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+min_spp = int(sys.argv[5]) if len(sys.argv) > 5 else spp
 if isinstance(spec, dict):
     keys = list(spec)
     spec = [dict(zip(keys, combo)) for combo in itertools.product(*[spec[k] for k in keys])]
@@ -19,7 +23,7 @@ if mesh_n > 0:
     sc, cam = scenes.dragon_box_scene(pos, nrm)
 else:
     sc, cam = scenes.cornell_scene(size, size) if mesh_n == 0 else scenes.box_scene()
-opt = scenes.options(size, size, spp, spp)
+opt = scenes.options(size, size, min_spp, spp)
 touched = set()
 for env in spec:
     for k in touched:
@@ -35,6 +39,6 @@ for env in spec:
         if best is None or st["kernel_ms"] < best["kernel_ms"]:
             best = st
     s.close()
-    print(env, "%.1f Msamples/s  kernel %.0f ms  %.1f walks per wave step  %d shading passes  rays/sample %.2f  nodes/ray %.1f" % (
-        size * size * spp / best["kernel_ms"] / 1e3, best["kernel_ms"], (best["node_visits"] + best["leaf_tests"]) / max(best["wave_steps"], 1),
+    print(env, "%.1f Msamples/s  (%.1f %% of the samples drawn)  kernel %.1f ms  %.1f walks per wave step  %d shading passes  rays/sample %.2f  nodes/ray %.1f" % (
+        size * size * spp / best["kernel_ms"] / 1e3, 100.0 * best["samples"] / (size * size * spp), best["kernel_ms"], (best["node_visits"] + best["leaf_tests"]) / max(best["wave_steps"], 1),
         best["shading_passes"], best["rays_traced"] / max(best["samples"], 1), best["node_visits"] / max(best["rays_traced"], 1)), flush=True)

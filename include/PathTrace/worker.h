@@ -43,7 +43,7 @@ Image<> processItem(const WorkItem &item, RandomEngine &re);
 
 // Renders the whole frame.  All tiles are in flight on the GPU at once; every pixel has its own engine, seeded from one
 // random base seed per call ($PATHTRACE_SEED fixes it).  progress_callback(completed, total) is called once per tile, in
-// order, from the calling thread.  worker_count is accepted for source compatibility and ignored.
+// order, from the calling thread.  worker_count (threads in the reference) caps the number of device replicas of the scene that take part (0 = all of them).
 Image<> processJob(
   const FrameRenderJob &job, const std::function<void(int, int)> &progress_callback = [](int, int) {}, int worker_count = 0);
 

@@ -384,7 +384,9 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg, const 
     cfg.burst_steps = std::min(std::max(env_int("PT_BURST", (cfg.in_lds && slots_per_wave >= 64U) ? 12 : 24), 1), 64);
     // Lanes that wait for the rare step (leaves) before it runs: 2 -> 374, 4 -> 396, 8 -> 414, 12 -> 415 Msamples/s on the benchmark frame; a
     // wavefront with 16 slots cannot wait for 8 of them (128 x 128, 180 k triangles: 8 -> 54, 4 -> 59, 2 -> 62 Msamples/s)
-    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", cfg.in_lds ? 8 : static_cast<int>(std::min<uint32_t>(std::max<uint32_t>(slots_per_wave / 8U, 2U), 8U))), 1), 64);
+    // Scenes in LDS (a leaf test is a larger share of a walk of 7-10 nodes): 8 -> 685 / 1160, 16 -> 724 / 1201, 24 -> 729 / 1193, 32 -> 707 / 1189 Msamples/s on
+    // Cornell / Box with full rows (profiles/r03_lds_scene_knobs.txt); wavefronts with less than a row of slots keep 8
+    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", cfg.in_lds ? (slots_per_wave >= 64U ? 16 : 8) : static_cast<int>(std::min<uint32_t>(std::max<uint32_t>(slots_per_wave / 8U, 2U), 8U))), 1), 64);
     const uint32_t rows = (slots_per_wave + 63U) / 64U;
     const uint32_t total = waves * rows * 64U;
     const uint32_t rays_per_slot = 1U + s->dev.n_lights + s->dev.n_object_samples;

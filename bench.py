@@ -344,7 +344,7 @@ def run_rank(args):
     # work in per-wave registers; the library then reads two HIP events recorded around the launch and the counters (128 KB) back.
     def timed(the_job, warmup, steps):
         for _ in range(warmup):
-            the_job.render()
+            the_job.render(want_stats=not standin)  # (the same call as a timed step: the first read-back of the counters sets up the runtime's staging buffers, 6-9 ms once)
         sync()
         t_begin = time.perf_counter()
         st = None

@@ -1,6 +1,6 @@
 """Knob sweep on one scene (the environment is read when a Scene is created).
 
-    python tools/sweep.py <mesh_n | 0 = cornell | -1 = box> <spp> "<list of dicts of env settings, or a dict of lists (grid)>" [size] [min_spp]
+    python tools/sweep.py <mesh_n | 0 = cornell | -1 = box> <spp> "<list of dicts of env settings, or a dict of lists (grid)>" [size] [min_spp] [copies_per_side]
 
 With min_spp < spp the per-pixel estimator may stop early (adaptive sampling); the rate is then on the max-spp basis and the share of
 the samples really drawn is printed.
@@ -15,12 +15,13 @@ spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 spec = eval(sys.argv[3]) if len(sys.argv) > 3 else [{}]
 size = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 min_spp = int(sys.argv[5]) if len(sys.argv) > 5 else spp
+copies = int(sys.argv[6]) if len(sys.argv) > 6 else 1  # 4 = BASELINE.json configs[4]: 16 copies of the mesh in an enlarged box
 if isinstance(spec, dict):
     keys = list(spec)
     spec = [dict(zip(keys, combo)) for combo in itertools.product(*[spec[k] for k in keys])]
 if mesh_n > 0:
     pos, nrm = scenes.bumpy_sphere_mesh(mesh_n, mesh_n, scenes.DRAGON_BOX_TRANSFORM)
-    sc, cam = scenes.dragon_box_scene(pos, nrm)
+    sc, cam = scenes.dragon_box_scene(pos, nrm) if copies <= 1 else scenes.dragon_grid_scene(pos, nrm, grid=copies)
 else:
     sc, cam = scenes.cornell_scene(size, size) if mesh_n == 0 else scenes.box_scene()
 opt = scenes.options(size, size, min_spp, spp)

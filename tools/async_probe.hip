@@ -8,6 +8,8 @@
 // request the next record, the others sit the iteration out -- no vmcnt wait anywhere.
 //
 //   mode 0: lockstep (registers, s_waitcnt vmcnt(0) before use)      mode 1: per-lane arrival through LDS sentinels
+//   mode 2: lockstep, but the record comes quad-cooperatively (one 64-byte request per quad and record instead of four 16-byte requests per lane)
+//           straight into LDS and is read back by its lane: a quarter of the L1 look-ups for one more LDS round trip per hop
 // Access pattern: a hop goes to a COLD record (uniform over `cold` records: HBM) with probability p_cold/256, else to a HOT one (uniform
 // over `hot` records: L1/L2).  The next index depends on the record just read.  Every record's words satisfy w[k] = hash(i) + k (low 31
 // bits), which lets mode 1 count torn records (a quarter seen half-written).
@@ -72,10 +74,10 @@ __device__ __forceinline__ uint32_t next_index(uint32_t &rng, uint32_t mix, uint
 template<int MODE>
 __global__ __launch_bounds__(256, 4) void chase(const u4v *__restrict__ recs_, uint32_t hot_mask, uint32_t cold_mask, uint32_t p_cold, int iters, int alu,
                                                  unsigned long long *out) {
-    __shared__ __align__(16) unsigned char lds_raw[4 * 4096];
+    __shared__ __align__(16) unsigned char lds_raw[4 * 4224];
     glb_u4 recs = (glb_u4)recs_;
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
-    unsigned char *region = lds_raw + wib * 4096;
+    unsigned char *region = lds_raw + wib * 4224;
     lds_u4 mine = (lds_u4)(u4v *)region + lane; // quarter q at mine[64 * q]
     uint32_t rng = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
     const uint32_t hot_base = cold_mask + 1u; // the hot records lie behind the cold ones
@@ -94,6 +96,44 @@ __global__ __launch_bounds__(256, 4) void chase(const u4v *__restrict__ recs_, u
             p = recs + 4 * (size_t)idx;
             r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3];
         }
+    }
+    else if(MODE == 2) {
+        // quad-cooperative fetch straight into LDS: instruction i brings the record of the quad's lane i (lane p its quarter p: one 64-byte
+        // request per quad instead of four 16-byte ones per lane), then every lane reads its own record back (regions padded by 16 bytes:
+        // the records of a quad's four lanes would otherwise start in the same bank)
+        const uint32_t qoff = (lane & 3u) * 16u;
+        unsigned char *rd = region + (lane & 3u) * 1040u + (lane >> 2) * 64u;
+        lds_u4 back = (lds_u4)(u4v *)rd;
+        uint32_t off = idx * 64u;
+#pragma unroll 1
+        for(int it = 0; it <= iters; it++) {
+            {
+                const uint32_t o0 = __builtin_amdgcn_update_dpp(0u, off, 0x00, 0xf, 0xf, false) + qoff;
+                const uint32_t o1 = __builtin_amdgcn_update_dpp(0u, off, 0x55, 0xf, 0xf, false) + qoff;
+                const uint32_t o2 = __builtin_amdgcn_update_dpp(0u, off, 0xaa, 0xf, 0xf, false) + qoff;
+                const uint32_t o3 = __builtin_amdgcn_update_dpp(0u, off, 0xff, 0xf, 0xf, false) + qoff;
+                const char __attribute__((address_space(1))) *base = (const char __attribute__((address_space(1))) *)recs;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + o0), (__attribute__((address_space(3))) void *)(region + 0), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + o1), (__attribute__((address_space(3))) void *)(region + 1040), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + o2), (__attribute__((address_space(3))) void *)(region + 2080), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + o3), (__attribute__((address_space(3))) void *)(region + 3120), 16, 0, 0);
+            }
+            if(it == iters) {
+                break;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+            const u4v r0 = back[0], r1 = back[1], r2 = back[2], r3 = back[3];
+            const uint32_t h = hash32(idx);
+            if(r0.x != (h & 0x7fffffffu) || r3.w != ((h + 15) & 0x7fffffffu)) {
+                torn++;
+            }
+            const uint32_t m = work(r0, r1, r2, r3, alu);
+            acc += m;
+            hops++;
+            idx = next_index(rng, r0.x ^ m, hot_mask, cold_mask, p_cold, hot_base);
+            off = idx * 64u;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0000);
     }
     else {
         const u4v s = {SENT, SENT, SENT, SENT};
@@ -164,11 +204,11 @@ int main(int argc, char **argv) {
     printf("%d CUs, %d iterations per wavefront, 4 workgroups of 256 per CU\n", cus, iters);
     for(int wg_per_cu : {4, 1}) {
         for(int alu : {40, 120}) {
-            for(uint32_t hot_n : {256u, 65536u}) {
+            for(uint32_t hot_n : {256u, 4096u, 65536u}) {
                 for(uint32_t p_cold : {0u, 4u, 16u, 64u}) {
-                    double rate[2] = {0, 0};
+                    double rate[3] = {0, 0, 0};
                     unsigned long long torn_total = 0, hops1 = 0;
-                    for(int mode = 0; mode < 2; mode++) {
+                    for(int mode = 0; mode < 3; mode++) {
                         CHECK(hipMemset(out, 0, 64));
                         const dim3 grid(cus * wg_per_cu);
                         for(int rep = 0; rep < 2; rep++) { // first run warms up
@@ -177,8 +217,11 @@ int main(int argc, char **argv) {
                             if(mode == 0) {
                                 hipLaunchKernelGGL(chase<0>, grid, dim3(256), 0, 0, recs, hot_n - 1, cold_n - 1, p_cold, iters, alu, out);
                             }
-                            else {
+                            else if(mode == 1) {
                                 hipLaunchKernelGGL(chase<1>, grid, dim3(256), 0, 0, recs, hot_n - 1, cold_n - 1, p_cold, iters, alu, out);
+                            }
+                            else {
+                                hipLaunchKernelGGL(chase<2>, grid, dim3(256), 0, 0, recs, hot_n - 1, cold_n - 1, p_cold, iters, alu, out);
                             }
                             CHECK(hipEventRecord(e1));
                             CHECK(hipEventSynchronize(e1));
@@ -189,13 +232,15 @@ int main(int argc, char **argv) {
                         CHECK(hipMemcpy(h, out, 24, hipMemcpyDeviceToHost));
                         rate[mode] = (double)h[0] / (ms * 1e-3) * 1e-9;
                         if(mode == 1) {
-                            torn_total = h[1];
                             hops1 = h[0];
+                        }
+                        if(mode >= 1) {
+                            torn_total += h[1];
                         }
                     }
                     const double full = (double)cus * wg_per_cu * 256 * iters;
-                    printf("wg/CU %d alu %3d hot %6u p_cold %2u/256: lockstep %7.2f G hops/s, per-lane arrival %7.2f G hops/s (x%.2f; lanes hopping per iteration %.1f of 64; torn records %llu)\n",
-                           wg_per_cu, alu, hot_n, p_cold, rate[0], rate[1], rate[1] / rate[0], 64.0 * (double)hops1 / full, torn_total);
+                    printf("wg/CU %d alu %3d hot %6u p_cold %2u/256: lockstep %7.2f G hops/s, per-lane arrival %7.2f (x%.2f; lanes hopping per iteration %.1f of 64), quad-cooperative into LDS %7.2f (x%.2f); wrong records %llu\n",
+                           wg_per_cu, alu, hot_n, p_cold, rate[0], rate[1], rate[1] / rate[0], 64.0 * (double)hops1 / full, rate[2], rate[2] / rate[0], torn_total);
                     fflush(stdout);
                 }
             }

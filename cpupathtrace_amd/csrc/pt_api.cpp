@@ -312,6 +312,7 @@ int setup_path(pt_scene *s) {
     cfg.pass_q_low = std::max(env_int("PT_PASS_Q_LOW", 0), 0);
     cfg.early_ready = std::min(std::max(env_int("PT_EARLY_READY", 0), 0), 64 * PT_MAX_ROWS);
     cfg.compact_passes = env_int("PT_COMPACT", 1) != 0 ? 1 : 0;
+    cfg.debug_lanes = std::min(std::max(env_int("PT_DEBUG_LANES", 64), 1), 64);
     // (burst_steps and leaf_min depend on the job's size as well: ensure_path_workspace sets them per job and keeps the last job's here)
     cfg.burst_steps = 24;
     cfg.leaf_min = 8;

@@ -101,6 +101,7 @@ struct PtPathConfig {
     int pass_q_low;       // a pass may also start while the ring still holds rays, if it holds at most this many ...
     int early_ready;      // ... and this many slots are ready (0 = never: a pass waits for the ring to run empty)
     int compact_passes;   // a pass whose ready slots fit fewer chunks of 64 than they occupy rows runs over a list of them (pt_path.hip)
+    int debug_lanes;      // diagnostic: lanes of a wavefront that take rays (64)
     int burst_steps;      // traversal steps between two looks at the queue
     int first_lanes;      // slots per piece of the first round of streams (slots_per_wave is a multiple of it)
     int leaf_min;         // lanes that must stand on a leaf before the leaf code runs (while other lanes still have nodes to visit)
@@ -117,7 +118,7 @@ struct PtPathArgs {
     PtSlots S;
     PtStreams T;
     PtLocalQueue Q;
-    int rows, slots_per_wave, refill_idle, min_ready, burst_steps, leaf_min, ready_shift, pass_q_low, early_ready, compact_passes;
+    int rows, slots_per_wave, refill_idle, min_ready, burst_steps, leaf_min, ready_shift, pass_q_low, early_ready, compact_passes, debug_lanes;
     uint2 *spill;
     uint32_t spill_depth;
     uint32_t save_stride;

@@ -1004,6 +1004,8 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     // what the traversal loop needs, read once
     const int rows = A->rows, slots_per_wave = A->slots_per_wave, refill_idle = A->refill_idle, min_ready = A->min_ready, burst_steps = A->burst_steps,
               leaf_min = A->leaf_min, ready_shift = A->ready_shift, pass_q_low = A->early_ready > 0 ? A->pass_q_low : 0, early_ready = A->early_ready;
+    // diagnostic (PT_DEBUG_LANES): only the first `debug_lanes` lanes of a wavefront take rays -- throughput against walks per step with everything else equal
+    const unsigned long long lane_cap = A->debug_lanes >= 64 ? ~0ULL : ((1ULL << A->debug_lanes) - 1ULL);
     PtLocalQueue Q = A->Q;
     RootBox root;
     root.ref = A->sc.root_ref;
@@ -1273,7 +1275,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
             }
 
             // ---- 2. idle lanes: hand out queued rays; with the queue empty, see whether enough slots are ready for a shading pass --------
-            const unsigned long long idle_mask = __ballot(!active);
+            const unsigned long long idle_mask = __ballot(!active) & lane_cap;
             const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
             if(n_idle >= (uint32_t)refill_idle) {
                 if(ctx.q_count <= (uint32_t)pass_q_low && ctx.n_dead < n_slots) {
@@ -1290,7 +1292,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
                     const uint32_t need = live_share < (uint32_t)min_ready ? (live_share > 1u ? live_share : 1u) : (uint32_t)min_ready;
                     // (with rays left in the ring -- pass_q_low > 0 -- the pass is an early one: it tops the ring up before the lanes run dry, and
                     // is only worth its fixed price when `early_ready` slots take part)
-                    if(ctx.q_count == 0 ? (n_ready >= need || n_idle == 64u) : n_ready >= (uint32_t)early_ready) {
+                    if(ctx.q_count == 0 ? (n_ready >= need || n_idle == (uint32_t)__popcll(lane_cap)) : n_ready >= (uint32_t)early_ready) {
                         want_pass = true;
                         break;
                     }
@@ -1673,6 +1675,7 @@ void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCame
     a.pass_q_low = cfg.pass_q_low;
     a.early_ready = cfg.early_ready;
     a.compact_passes = cfg.compact_passes;
+    a.debug_lanes = cfg.debug_lanes;
     a.spill = cfg.spill;
     a.spill_depth = cfg.spill_depth;
     a.save_stride = (uint32_t)cfg.grid * 256u;

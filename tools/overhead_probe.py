@@ -1,5 +1,8 @@
+"""What a bench step costs outside the launch: wall time of ShardedJob.render (what bench.py times) against the launch duration by HIP events,
+for Box, Cornell and a 2 M-triangle mesh at 1024 x 1024 (profiles/r03_host_overhead.txt: 0.2-0.6 ms; the FIRST call that reads the counters back
+costs 6 ms more).      python tools/overhead_probe.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from cpupathtrace_amd import binding, scenes, sharding

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--ranks", default="all", help="'all' or how many ranks of each N to run (evenly spaced)")
     ap.add_argument("--env", action="append", default=[], help="dict of PT_* settings for a variant")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--tile", type=int, default=0, help="deal tiles of this many pixels per side instead of processJob's own (0): finer tiles even out what the ranks get")
     args = ap.parse_args()
     import torch
     from cpupathtrace_amd import binding, scenes, sharding
@@ -33,6 +34,9 @@ def main():
     sc, cam, label, gen_s = bench.build_workload(args.workload, args.size, args.size, args.mesh_n)
     opt = scenes.options(args.size, args.size, args.spp, args.spp)
     tiles = binding.job_tiles(args.size, args.size)
+    if args.tile > 0:
+        t = args.tile
+        tiles = np.array([(x, y, min(t, args.size - x), min(t, args.size - y)) for y in range(0, args.size, t) for x in range(0, args.size, t)], dtype=binding.TILE_DTYPE)
     dev = torch.device("cuda", 0)
     image = torch.zeros((args.size, args.size, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream

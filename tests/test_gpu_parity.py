@@ -779,3 +779,35 @@ def test_compacted_passes_render_the_same_frame(oracle_lib):
             by_rows.close()
             by_list.close()
             handle.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    {"PT_BURST": 1, "PT_LEAF_MIN": 64},
+    {"PT_REFILL_IDLE": 64, "PT_MIN_READY": 512},
+    {"PT_REFILL_IDLE": 1, "PT_MIN_READY": 1, "PT_READY_SHIFT": 3},
+    {"PT_PASS_Q_LOW": 64, "PT_EARLY_READY": 48},        # passes that start while the ring still holds rays
+    {"PT_PASS_Q_LOW": 1000, "PT_EARLY_READY": 1, "PT_BURST": 3},
+    {"PT_DEBUG_LANES": 5, "PT_REFILL_IDLE": 2},         # five lanes of a wavefront take rays
+    {"PT_ROWS": 2, "PT_BLOCKS_PER_CU": 1},
+    {"PT_ROWS": 3, "PT_FIRST_LANES": 4, "PT_COMPACT": 0},
+], ids=lambda e: ",".join("%s=%s" % (k[3:].lower(), v) for k, v in e.items()))
+def test_scheduler_knobs_do_not_change_the_frame(env):
+    """How a wavefront schedules its work -- burst length, refill and pass thresholds, early passes, rows of slots, lanes that take rays,
+    compacted passes -- decides WHEN a stream's next draw is made, never which: a 1024 x 1024 adaptive frame (several rows of slots per
+    wavefront, slots that die at different samples) is the same bit for bit under extreme settings, with the tree in HBM and in LDS."""
+    cases = [("meshbox", scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(24, 24, scenes.DRAGON_BOX_TRANSFORM)), scenes.options(1024, 1024, 3, 14)),
+             ("box", scenes.box_scene(), scenes.options(1024, 1024, 4, 12))]
+    for name, (desc, cam), opt in cases:
+        for lds_small in (1, 0):
+            plain = _scene_with_env(desc, PT_LDS_SMALL=lds_small)
+            tuned = _scene_with_env(desc, PT_LDS_SMALL=lds_small, **env)
+            try:
+                want, st0 = plain.process_job(cam, opt, base_seed=55, want_stats=True)
+                want = want.copy()
+                got, st1 = tuned.process_job(cam, opt, base_seed=55, want_stats=True)
+                assert_bits_equal(got, want, "%s (small trees %s): frame under %s" % (name, "in LDS" if lds_small else "in HBM", env))
+                assert st1["samples"] == st0["samples"] and st1["vertices"] == st0["vertices"] and st1["rays_traced"] == st0["rays_traced"]
+            finally:
+                plain.close()
+                tuned.close()

@@ -758,7 +758,9 @@ def test_compacted_passes_render_the_same_frame(oracle_lib):
     Which lane shades which slot must not matter: the frame equals the one rendered row by row (PT_COMPACT=0) bit for bit, both with the
     tree in HBM and with the scene in LDS, and equals the oracle on sampled pixels."""
     cases = [("mesh80k", scenes.dragon_box_scene(*scenes.bumpy_sphere_mesh(200, 200, scenes.DRAGON_BOX_TRANSFORM)), scenes.options(1024, 1024, 4, 24)),
-             ("box", scenes.box_scene(), scenes.options(1024, 1024, 8, 40))]
+             ("box", scenes.box_scene(), scenes.options(1024, 1024, 8, 40)),
+             # 14 light samples per vertex: the kernel with the 64-bit slot word (its waiting mask lives with the slot's state in HBM)
+             ("lit room", (_lit_room(12, _three_emitters), scenes.camera((0, 0, -3), (0, 0, 0), (0, 1, 0), 1.0, 1.0, -1.0)), scenes.options(1024, 1024, 3, 12))]
     for name, (desc, cam), opt in cases:
         by_rows = _scene_with_env(desc, PT_COMPACT=0)
         by_list = _scene_with_env(desc, PT_COMPACT=1)

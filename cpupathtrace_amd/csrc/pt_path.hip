@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
         root.hi[k] = A->sc.root_hi[k];
     }
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    // LDS of the workgroup: traversal stacks [STACK_LDS][256] | hit records [4 waves][rows * 64] | slot words [4 waves][rows * 64] | ready lists [4 waves][rows * 64] |
+    // LDS of the workgroup: traversal stacks [STACK_LDS][256] | hit records [4 waves][rows * 64] | slot words [4 waves][rows * 64] |
     // emitter and material tables (PT_LDS_TABLE_BYTES) | start step of every lane's walk | (small scenes) the whole tree and all triangle records
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
@@ -1028,9 +1028,6 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     at += (size_t)4 * n_slots * sizeof(uint2);
     typename SW::lds_ptr word_l = (typename SW::lds_ptr)reinterpret_cast<typename SW::T *>(at) + wave_in_block * n_slots;
     at += (size_t)4 * n_slots * sizeof(typename SW::T);
-    typedef unsigned short __attribute__((address_space(3))) *lds_u16_ptr;
-    lds_u16_ptr list_l = (lds_u16_ptr)reinterpret_cast<unsigned short *>(at) + wave_in_block * n_slots; // the ready slots of a compacted pass
-    at += (size_t)4 * n_slots * sizeof(unsigned short);
     float *cdf_l = reinterpret_cast<float *>(at);
     at += (size_t)PT_LDS_TABLE_MAX * sizeof(float);
     float4 *emis_l = reinterpret_cast<float4 *>(at);
@@ -1040,6 +1037,9 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
     float4 *materials_l = reinterpret_cast<float4 *>(at);
     at += (size_t)PT_LDS_TABLE_MAX * 4 * sizeof(float4);
     uint32_t __attribute__((address_space(3))) *born_l = (uint32_t __attribute__((address_space(3))) *)reinterpret_cast<uint32_t *>(at) + tid; // wave step at which the lane's walk began
+    // (the same kilobyte holds the list of ready slots of a compacted shading pass, one byte per slot of up to four rows, when the cost diagnostics are off)
+    typedef unsigned char __attribute__((address_space(3))) *lds_u8_ptr;
+    lds_u8_ptr list_l = (lds_u8_ptr)reinterpret_cast<unsigned char *>(at) + wave_in_block * 256u;
     at += (size_t)PT_COST_LDS_BYTES;
     float4 *lds_recs = reinterpret_cast<float4 *>(at); // (small scenes) every record, in the order of `recs`
     const bool cost_on = PT_COST_LDS_BYTES != 0 && A->T.cost != nullptr;
@@ -1183,14 +1183,14 @@ __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPat
             // well-filled pass keeps the rows.  (The first round of streams is dealt by row: no list before every row has had its turn.)
             uint32_t n_listed = 0;
             bool compact = false;
-            if(P->compact_passes != 0 && rows > 1 && ctx.first_rows == 0u) {
+            if(PT_COST_LDS_BYTES >= 1024 && !cost_on && P->compact_passes != 0 && rows > 1 && rows <= 4 && ctx.first_rows == 0u) {
                 uint32_t rows_used = 0;
                 for(uint32_t r = 0; r < (uint32_t)rows; r++) {
                     const typename SW::T word = word_l[r * 64 + lane];
                     const bool is_ready = !(SW::flags(word) & PT_F_DONE) && SW::pending(word) == 0;
                     const unsigned long long m = __ballot(is_ready);
                     if(is_ready) {
-                        list_l[n_listed + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = (unsigned short)(r * 64 + lane);
+                        list_l[n_listed + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = (unsigned char)(r * 64 + lane);
                     }
                     n_listed += (uint32_t)__popcll(m);
                     rows_used += m != 0ULL ? 1u : 0u;
@@ -1722,7 +1722,7 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
 
 size_t pt_path_lds_bytes(int wide, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
     const size_t scene = ((size_t)n_lds_pairs + n_lds_leaf_records) * 64;
-    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t)) + sizeof(unsigned short)) + PT_LDS_TABLE_BYTES + PT_COST_LDS_BYTES + scene;
+    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t))) + PT_LDS_TABLE_BYTES + PT_COST_LDS_BYTES + scene;
 }
 
 int pt_path_blocks_per_cu(int wide, int in_lds, size_t lds_bytes) {

@@ -296,12 +296,16 @@ int setup_path(pt_scene *s) {
         return PT_OK;
     }
     cfg.in_lds = (s->dev.n_lds_pairs == s->dev.n_pairs && s->dev.n_lds_tris == s->dev.n_tris && s->dev.n_lds_pairs + s->dev.n_lds_tris > 0) ? 1 : 0;
-    // 8 stack entries per lane in LDS (16 KB per workgroup) let four workgroups share a CU; deeper walks use the HBM spill area
-    cfg.stack_lds = 8;
+    // 8 stack entries per lane in LDS (16 KB per workgroup) let four workgroups share a CU; deeper walks use the HBM spill area.  A scene
+    // staged in LDS that leaves no room for four workgroups that way gets a window of 4 entries (pt_path.hip, PT_PATH_STACK_LDS_SMALL)
     cfg.wide = s->dev.n_lights + s->dev.n_object_samples > 8U ? 1 : 0;
     cfg.rows = std::min(std::max(env_int("PT_ROWS", 4), 1), PT_MAX_ROWS);
-    cfg.lds_bytes = pt_path_lds_bytes(cfg.wide, cfg.rows, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.pair_base : 0U);
-    const int per_cu = pt_path_blocks_per_cu(cfg.wide, cfg.in_lds, cfg.lds_bytes);
+    cfg.stack_lds = pt_path_stack_lds(cfg.in_lds, pt_path_lds_bytes(cfg.wide, cfg.rows, 8, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.pair_base : 0U));
+    if(cfg.in_lds && env_int("PT_STACK_WINDOW", 0) > 0) {
+        cfg.stack_lds = env_int("PT_STACK_WINDOW", 0) <= 4 ? 4 : 8; // (A/B: force the window of a scene in LDS)
+    }
+    cfg.lds_bytes = pt_path_lds_bytes(cfg.wide, cfg.rows, cfg.stack_lds, cfg.in_lds ? s->dev.n_lds_pairs : 0U, cfg.in_lds ? s->dev.pair_base : 0U);
+    const int per_cu = pt_path_blocks_per_cu(cfg);
     const int limit = env_int("PT_BLOCKS_PER_CU", 0);
     s->path_blocks_per_cu = (limit > 0 && limit < per_cu) ? limit : per_cu;
     // a walk's stack holds at most one parked node per level of the tree and the sentinel at its bottom (pt_path.hip); what does not fit the LDS window spills

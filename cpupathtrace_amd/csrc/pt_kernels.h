@@ -131,8 +131,9 @@ struct PtPathArgs {
 // fills *host_args (which must stay valid until the launch has been issued), copies it to d_args on `stream` and launches
 void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams,
                     PtLocalQueue queue, const PtPathConfig &cfg, float4 *image, PtDevCounters *counters, PtPathArgs *host_args, PtPathArgs *d_args);
-int pt_path_blocks_per_cu(int wide, int in_lds, size_t lds_bytes);
-size_t pt_path_lds_bytes(int wide, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records); // leaf records: triangles + 1 spare + spheres, 0 = scene not in LDS
+int pt_path_blocks_per_cu(const PtPathConfig &cfg); // resident workgroups per CU of the instantiation cfg selects (wide, in_lds, stack_lds) with cfg.lds_bytes
+size_t pt_path_lds_bytes(int wide, int rows, int stack_lds, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records); // leaf records: triangles + 1 spare + spheres, 0 = scene not in LDS
+int pt_path_stack_lds(int in_lds, size_t lds_bytes_with_default_window); // entries of the stack window: 8, or 4 for a scene in LDS that would not leave room for four workgroups per CU
 // Scene::getIntersection for n rays (6 floats each): out[i] = (bits t, ref)
 // diagnostic (tools/replay_probe.py): the traversal alone over the rays a render left in its rings; returns the resident workgroups per CU
 int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueue &Q, uint32_t n_logs, uint32_t parts, int waves_per_simd, const PtPathConfig &cfg,

@@ -986,6 +986,10 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
 // ---- the kernel -------------------------------------------------------------------------------------------------------------------------
 
 #define PT_PATH_STACK_LDS 8 /* entries of a lane's traversal stack kept in LDS (16 KB per workgroup: four workgroups share a CU); deeper ones spill to HBM */
+// A scene staged in LDS whose records leave no room for four workgroups per CU beside an 8-entry window gets a 4-entry one (its tree has at most
+// 384 records: few walks go deeper, and those spill as on any tree).  176 / 98 / 72 triangles in the benchmark's box: 600 -> 757, 855 -> 949, 802 -> 862
+// Msamples/s; where four workgroups fit anyway the small window costs 2-4 % (Cornell 718 -> 705), and on trees in HBM 9 % (profiles/r03_stack_window_ab.txt).
+#define PT_PATH_STACK_LDS_SMALL 4
 #ifndef PT_COST_LDS_BYTES
 #define PT_COST_LDS_BYTES 1024 /* one word per lane: the wave step at which its walk began (stream cost diagnostics); 0 in builds that need the LDS */
 #endif
@@ -993,9 +997,8 @@ PT_D void shade_row(const PtDevScene &sc, const PtDevCamera &cam, const PtDevOpt
 #define PT_PATH_WAVES 4 /* 128 VGPRs: the traversal loop has no spills there; three waves per SIMD hide less of the node-fetch latency (profiles/) */
 #endif
 
-template<bool WIDE, bool IN_LDS>
+template<bool WIDE, bool IN_LDS, int STACK_LDS>
 __global__ __launch_bounds__(256, PT_PATH_WAVES) void pt_path_kernel(const PtPathArgs *__restrict__ args) {
-    constexpr int STACK_LDS = PT_PATH_STACK_LDS;
     typedef SlotWord<WIDE> SW;
     // The argument block is read-only for the whole launch: it is addressed as CONSTANT memory (scalar loads; and pointers loaded from
     // constant memory are known to be global ones, so everything reached through them stays global_load / global_store).
@@ -1616,16 +1619,16 @@ int launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQueu
     return blocks;
 }
 
-template<bool WIDE, bool IN_LDS>
+template<bool WIDE, bool IN_LDS, int STACK_LDS>
 void launch_path(hipStream_t stream, const PtPathConfig &cfg, const PtPathArgs *d_args) {
-    hipLaunchKernelGGL((pt_path_kernel<WIDE, IN_LDS>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, d_args);
+    hipLaunchKernelGGL((pt_path_kernel<WIDE, IN_LDS, STACK_LDS>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, stream, d_args);
 }
 
-template<bool WIDE, bool IN_LDS>
-int occupancy(size_t lds_bytes) {
+template<bool WIDE, bool IN_LDS, int STACK_LDS>
+void occupancy(size_t lds_bytes, int *out) {
     int blocks = 0;
-    const hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_path_kernel<WIDE, IN_LDS>, 256, lds_bytes);
-    return (err != hipSuccess || blocks < 1) ? 1 : blocks;
+    const hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pt_path_kernel<WIDE, IN_LDS, STACK_LDS>, 256, lds_bytes);
+    *out = (err != hipSuccess || blocks < 1) ? 1 : blocks;
 }
 
 template<int STACK_LDS, bool IN_LDS>
@@ -1636,24 +1639,33 @@ void launch_closest(hipStream_t stream, const PtDevScene &scene, const float *ra
 
 } // namespace
 
-#define PT_DISPATCH_PATH(fn, cfg, ...)                             \
-    do {                                                           \
-        if((cfg).in_lds) {                                         \
-            if((cfg).wide) {                                       \
-                fn<true, true>(__VA_ARGS__);                       \
-            }                                                      \
-            else {                                                 \
-                fn<false, true>(__VA_ARGS__);                      \
-            }                                                      \
-        }                                                          \
-        else {                                                     \
-            if((cfg).wide) {                                       \
-                fn<true, false>(__VA_ARGS__);                      \
-            }                                                      \
-            else {                                                 \
-                fn<false, false>(__VA_ARGS__);                     \
-            }                                                      \
-        }                                                          \
+// the instantiations of the path kernel: slot word (compact | wide) x records (HBM | LDS) x stack window (8 entries; 4 for scenes in LDS that need the room)
+#define PT_DISPATCH_PATH(fn, cfg, ...)                                              \
+    do {                                                                            \
+        if((cfg).in_lds && (cfg).stack_lds == PT_PATH_STACK_LDS_SMALL) {            \
+            if((cfg).wide) {                                                        \
+                fn<true, true, PT_PATH_STACK_LDS_SMALL>(__VA_ARGS__);               \
+            }                                                                       \
+            else {                                                                  \
+                fn<false, true, PT_PATH_STACK_LDS_SMALL>(__VA_ARGS__);              \
+            }                                                                       \
+        }                                                                           \
+        else if((cfg).in_lds) {                                                     \
+            if((cfg).wide) {                                                        \
+                fn<true, true, PT_PATH_STACK_LDS>(__VA_ARGS__);                     \
+            }                                                                       \
+            else {                                                                  \
+                fn<false, true, PT_PATH_STACK_LDS>(__VA_ARGS__);                    \
+            }                                                                       \
+        }                                                                           \
+        else {                                                                      \
+            if((cfg).wide) {                                                        \
+                fn<true, false, PT_PATH_STACK_LDS>(__VA_ARGS__);                    \
+            }                                                                       \
+            else {                                                                  \
+                fn<false, false, PT_PATH_STACK_LDS>(__VA_ARGS__);                   \
+            }                                                                       \
+        }                                                                           \
     } while(0)
 
 void pt_launch_path(hipStream_t stream, const PtDevScene &scene, const PtDevCamera &camera, const PtDevOptions &options, PtSlots slots, PtStreams streams,
@@ -1701,7 +1713,10 @@ void pt_launch_closest(hipStream_t stream, const PtDevScene &scene, const float 
     if(n == 0) {
         return;
     }
-    if(cfg.in_lds) {
+    if(cfg.in_lds && cfg.stack_lds == PT_PATH_STACK_LDS_SMALL) {
+        launch_closest<PT_PATH_STACK_LDS_SMALL, true>(stream, scene, rays6, n, out, cfg);
+    }
+    else if(cfg.in_lds) {
         launch_closest<PT_PATH_STACK_LDS, true>(stream, scene, rays6, n, out, cfg);
     }
     else {
@@ -1720,14 +1735,18 @@ int pt_launch_replay(hipStream_t stream, const PtDevScene &scene, const PtLocalQ
     }
 }
 
-size_t pt_path_lds_bytes(int wide, int rows, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
+size_t pt_path_lds_bytes(int wide, int rows, int stack_lds, uint32_t n_lds_pairs, uint32_t n_lds_leaf_records) {
     const size_t scene = ((size_t)n_lds_pairs + n_lds_leaf_records) * 64;
-    return (size_t)PT_PATH_STACK_LDS * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t))) + PT_LDS_TABLE_BYTES + PT_COST_LDS_BYTES + scene;
+    return (size_t)stack_lds * 256 * sizeof(uint2) + (size_t)4 * rows * 64 * (sizeof(uint2) + (wide ? sizeof(unsigned long long) : sizeof(uint32_t))) + PT_LDS_TABLE_BYTES + PT_COST_LDS_BYTES + scene;
 }
 
-int pt_path_blocks_per_cu(int wide, int in_lds, size_t lds_bytes) {
-    if(in_lds) {
-        return wide ? occupancy<true, true>(lds_bytes) : occupancy<false, true>(lds_bytes);
-    }
-    return wide ? occupancy<true, false>(lds_bytes) : occupancy<false, false>(lds_bytes);
+int pt_path_blocks_per_cu(const PtPathConfig &cfg) {
+    int blocks = 1;
+    PT_DISPATCH_PATH(occupancy, cfg, cfg.lds_bytes, &blocks);
+    return blocks;
+}
+
+int pt_path_stack_lds(int in_lds, size_t lds_bytes_with_default_window) {
+    // (four workgroups of the path kernel share the 160 KB of a CU when each stays within 40 KB)
+    return (in_lds && lds_bytes_with_default_window > 40960) ? PT_PATH_STACK_LDS_SMALL : PT_PATH_STACK_LDS;
 }

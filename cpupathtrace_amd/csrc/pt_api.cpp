@@ -386,12 +386,24 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg, const 
     // Steps between two looks at the ring.  Trees in HBM: 8 -> 397, 12 -> 407, 16 -> 412, 24 -> 422, 32 -> 421 Msamples/s on the benchmark frame
     // (round 3 made the step cheaper, looking at the ring costs what it did); scenes in LDS keep 12 on a full grid (Cornell: 700 against 659
     // with 24) and take 24 when a wavefront has less than a row of slots (the reference's benchmark program, 128 x 128: 136 -> 176 Msamples/s).
-    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", (cfg.in_lds && slots_per_wave >= 64U) ? 12 : 24), 1), 64);
+    // Shallower trees in HBM have shorter walks, and looking at the ring more often pays again (full rows, profiles/r03_tree_size_knobs.txt):
+    // 3 K triangles (14 levels) 12 -> 625 against 610 with 24; 20 K (17 levels) 16 -> 589 against 564; from 180 K (22 levels) on 24 wins.
+    int burst_default = 24;
+    if(slots_per_wave >= 64U) {
+        burst_default = cfg.in_lds ? 12 : (s->depth <= 14U ? 12 : (s->depth <= 18U ? 16 : 24));
+    }
+    cfg.burst_steps = std::min(std::max(env_int("PT_BURST", burst_default), 1), 64);
     // Lanes that wait for the rare step (leaves) before it runs: 2 -> 374, 4 -> 396, 8 -> 414, 12 -> 415 Msamples/s on the benchmark frame; a
     // wavefront with 16 slots cannot wait for 8 of them (128 x 128, 180 k triangles: 8 -> 54, 4 -> 59, 2 -> 62 Msamples/s)
     // Scenes in LDS (a leaf test is a larger share of a walk of 7-10 nodes): 8 -> 685 / 1160, 16 -> 724 / 1201, 24 -> 729 / 1193, 32 -> 707 / 1189 Msamples/s on
     // Cornell / Box with full rows (profiles/r03_lds_scene_knobs.txt); wavefronts with less than a row of slots keep 8
-    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", cfg.in_lds ? (slots_per_wave >= 64U ? 16 : 8) : static_cast<int>(std::min<uint32_t>(std::max<uint32_t>(slots_per_wave / 8U, 2U), 8U))), 1), 64);
+    // trees in HBM of up to 24 levels (720 K triangles) with full rows: 12 instead of 8 brings 1-4 % (3 K triangles 599 -> 610, 20 K 552 -> 564, 180 K 523 -> 530,
+    // 720 K 483 -> 488); the benchmark's 30 levels keep 8 (430 against 425)
+    int leaf_default = cfg.in_lds ? (slots_per_wave >= 64U ? 16 : 8) : static_cast<int>(std::min<uint32_t>(std::max<uint32_t>(slots_per_wave / 8U, 2U), 8U));
+    if(!cfg.in_lds && slots_per_wave >= 64U && s->depth <= 24U) {
+        leaf_default = 12;
+    }
+    cfg.leaf_min = std::min(std::max(env_int("PT_LEAF_MIN", leaf_default), 1), 64);
     const uint32_t rows = (slots_per_wave + 63U) / 64U;
     const uint32_t total = waves * rows * 64U;
     const uint32_t rays_per_slot = 1U + s->dev.n_lights + s->dev.n_object_samples;
@@ -1089,10 +1101,16 @@ int pt_scene_create(int device, const pt_scene_desc *d, pt_scene **out) {
     dev.n_emis = s->n_emissive;
     dev.n_materials = d->n_materials;
     dev.n_object_samples = static_cast<uint32_t>(object_sample_count);
-    // LDS staging: a scene whose whole tree and triangle records fit in 24 KiB lives in LDS entirely (the path kernel's IN_LDS
-    // variant); an LDS copy of only the top of a larger tree was measured in round 1 and does not pay.
+    // LDS staging: a scene whose whole tree and leaf records fit in LDS NEXT TO everything else a workgroup keeps there, four workgroups
+    // to the CU, lives in LDS entirely (the path kernel's IN_LDS variant): up to 15.8 KB of records with the small stack window, i.e. about
+    // 120 triangles.  Larger ones are read through the caches like any tree: staged at three workgroups per CU they are slower than that
+    // (176 triangles: 754 against 785 Msamples/s; at two, 256 triangles: 581 against 715 -- profiles/r03_lds_threshold.txt; round 2 staged up to
+    // 24 KB).  An LDS copy of only the top of a larger tree was measured in round 1 and does not pay.  PT_LDS_SMALL_BYTES overrides the limit.
     const size_t small_bytes = (static_cast<size_t>(n_pairs) + pair_base) * 64;
-    if(small_bytes <= 24 * 1024 && env_int("PT_LDS_SMALL", 1) != 0) {
+    const int wide_word = d->n_point_lights + static_cast<uint32_t>(object_sample_count) > 8U ? 1 : 0;
+    const size_t other_lds = pt_path_lds_bytes(wide_word, std::min(std::max(env_int("PT_ROWS", 4), 1), PT_MAX_ROWS), 4, 0U, 0U);
+    const size_t room = other_lds < 40960 ? 40960 - other_lds : 0;
+    if(small_bytes <= static_cast<size_t>(std::max(env_int("PT_LDS_SMALL_BYTES", static_cast<int>(room)), 0)) && env_int("PT_LDS_SMALL", 1) != 0) {
         dev.n_lds_pairs = n_pairs;
         dev.n_lds_tris = d->n_triangles;
     }

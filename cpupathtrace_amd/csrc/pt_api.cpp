@@ -386,11 +386,16 @@ int ensure_path_workspace(pt_scene *s, uint32_t n, PtPathConfig *out_cfg, const 
     // Steps between two looks at the ring.  Trees in HBM: 8 -> 397, 12 -> 407, 16 -> 412, 24 -> 422, 32 -> 421 Msamples/s on the benchmark frame
     // (round 3 made the step cheaper, looking at the ring costs what it did); scenes in LDS keep 12 on a full grid (Cornell: 700 against 659
     // with 24) and take 24 when a wavefront has less than a row of slots (the reference's benchmark program, 128 x 128: 136 -> 176 Msamples/s).
-    // Shallower trees in HBM have shorter walks, and looking at the ring more often pays again (full rows, profiles/r03_tree_size_knobs.txt):
-    // 3 K triangles (14 levels) 12 -> 625 against 610 with 24; 20 K (17 levels) 16 -> 589 against 564; from 180 K (22 levels) on 24 wins.
+    // Shallower trees in HBM have shorter walks, and looking at the ring more often pays again (profiles/r03_tree_size_knobs.txt): 160-330
+    // triangles (10, 11 levels) 12 -> 795 / 764 against 788 / 756 with 24; 3 K (14 levels) 16 -> 662 against 610 (one and two rows of slots:
+    // 522 against 502, 621 against 575); 20 K (17 levels) 16 -> 589 against 564; from 180 K (22 levels) on 24 wins.  Scenes in LDS: 12 with
+    // several rows of slots (Cornell 1024 x 1024: 700 against 659, 724 x 724: 656 against 635), 24 with one (256 x 256: 221 against 218, Box 406 against 373).
     int burst_default = 24;
-    if(slots_per_wave >= 64U) {
-        burst_default = cfg.in_lds ? 12 : (s->depth <= 14U ? 12 : (s->depth <= 18U ? 16 : 24));
+    if(cfg.in_lds) {
+        burst_default = slots_per_wave > 64U ? 12 : 24;
+    }
+    else if(slots_per_wave >= 64U) {
+        burst_default = s->depth <= 12U ? 12 : (s->depth <= 18U ? 16 : 24);
     }
     cfg.burst_steps = std::min(std::max(env_int("PT_BURST", burst_default), 1), 64);
     // Lanes that wait for the rare step (leaves) before it runs: 2 -> 374, 4 -> 396, 8 -> 414, 12 -> 415 Msamples/s on the benchmark frame; a
